@@ -1,0 +1,207 @@
+/*
+ * hsp.h -- C ABI of libhsp.so, the MI355X (gfx950) kernel library behind the
+ * HierSpeech++ waveform-generation hot path.
+ *
+ * The reference (liuhuang31/Megatts2_HierSpeechpp) has no FFI/plugin layer: its hot
+ * path is a chain of torch ops called from Python nn.Modules.  The
+ * entry points below are therefore "what the reference's FFI for this path would
+ * bind": one launcher per fused op, plain pointers + sizes + a hipStream_t, no torch
+ * types.  Each one names the reference code it replaces.  The Python host side
+ * (megatts2_hierspeechpp_amd/_lib.py) binds them with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all tensors fp32, device pointers, layout (B, C, T) with T fastest unless stated;
+ *     strides are in ELEMENTS
+ *   - launchers never allocate, never synchronise, never throw; they return 0 on
+ *     success, HSP_EINVAL (-1) on bad arguments, or the positive hipError_t of the launch
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - thread-compatible: no mutable global state
+ */
+#ifndef HSP_H_
+#define HSP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSP_VERSION 100 /* 0.1.0 */
+#define HSP_EINVAL (-1)
+
+int hsp_version(void);
+/* gfx arch string the library was compiled for ("gfx950") */
+const char* hsp_arch(void);
+
+/* ---------------------------------------------------------------- conv1d (fused) */
+
+/* prologue applied to the conv INPUT while it is staged in LDS */
+enum {
+  HSP_PRO_NONE = 0,
+  HSP_PRO_LRELU = 1, /* F.leaky_relu(x, slope): DBlock, hierspeechpp_speechsynthesizer.py:336 */
+  HSP_PRO_ACT1D = 2, /* Activation1d(SnakeBeta): alias_free_torch/act.py:23-28 + activations.py:107-119 */
+  HSP_PRO_SILU = 3   /* nn.SiLU before a Linear: modules.py:402-405 (direct kernel only) */
+};
+
+/* pointwise function applied to (acc + bias) in the epilogue */
+enum {
+  HSP_ACT_NONE = 0,
+  HSP_ACT_TANH = 1,      /* Generator tail, hierspeechpp_speechsynthesizer.py:450 */
+  HSP_ACT_GELU_TANH = 2, /* FFN_Conv, modules.py:384,400 */
+  HSP_ACT_RELU = 3,      /* attentions.FFN, attentions.py:292 */
+  HSP_ACT_MISH = 4,      /* StyleEncoder, styleencoder.py:9-10 */
+  HSP_ACT_SILU = 5,      /* cond_block, hierspeechpp_speechsynthesizer.py:72 */
+  HSP_ACT_SOFTPLUS = 6
+};
+
+/* how packed weight rows map to output channels */
+enum {
+  HSP_ROWS_PLAIN = 0,    /* row m -> channel m */
+  HSP_ROWS_GATE_WN = 1,  /* rows come in 32-blocks (a, b): out = tanh(a)*sigmoid(b); commons.py:107-114 */
+  HSP_ROWS_GATE_GLU = 2, /* out = a*sigmoid(b); styleencoder.py:26-31 */
+  HSP_ROWS_SHUFFLE = 3   /* ConvTranspose1d as polyphase conv: row m -> (co = m / up, phase = m % up) */
+};
+
+enum { HSP_MASK_NONE = 0, HSP_MASK_PRE = 1, HSP_MASK_POST = 2, HSP_MASK_BOTH = 3 };
+
+/*
+ * y = epilogue( conv1d( prologue(x) ) )
+ *
+ * Replaces torch Conv1d / ConvTranspose1d / Linear call sites together with the
+ * elementwise work around them: hierspeechpp_speechsynthesizer.py:195-200 (Posterior
+ * SF encoder), :292-307 (SourceNetwork), :331-339 (DBlock), :380-384 (AMPBlock1),
+ * :430-450 (Generator); modules.py:156-175 (WN), :383-386 (FFN_Conv), :409-410 (DiT
+ * residuals), :461,473,486 (coupling); styleencoder.py:26-31,66-78.
+ *
+ * Weights are pre-folded (weight-norm) and packed by the host as w[K][Cin][w_ld] (w_ld =
+ * packed row count, a multiple of 4; a launch computes rows [0, M) of it) in the row
+ * order `rows` names.
+ *
+ * conv:     acc[m, t] = sum_{j<K} sum_{ci<Cin} w[j][ci][m] * xin[ci, t*stride + j*dil - pad]
+ *           xin = prologue(x) inside [0, Lin), 0 outside; x is read at
+ *           x + b*x_bs + ci*x_cs + i*x_ts
+ * epilogue: v = acc + bias[row] + cbias[b*cbias_bs + row]          (row = channel index
+ *               of the un-packed layer; GATE modes add both halves before gating)
+ *           v = act(v)                       | gate(v_a, v_b) in GATE modes
+ *           v *= mask[b*mask_bs + t]         if mask_mode & PRE
+ *           v *= cscale[b*cscale_bs + co]    if cscale
+ *           v *= scale
+ *           v += res[b*res_bs + co*res_cs + t]   if res
+ *           v *= mask[...]                   if mask_mode & POST
+ *           v += y[...]                      if accumulate
+ *           y[b*y_bs + co*y_cs + t] = v * post_scale
+ *           (SHUFFLE: co = m / up, t -> up*t + m % up - shuf_pad, bounds-checked to Lout)
+ */
+typedef struct hsp_conv1d_args {
+  /* input */
+  const float* x;
+  int64_t x_bs, x_cs, x_ts;
+  int32_t B, Cin, Lin;
+  /* packed weights */
+  const float* w;
+  int32_t K, M, dil, pad, stride;
+  int32_t w_ld; /* row count of the packed matrix w points into (>= M): lets a launch
+                   use a row sub-range [r0, r0+M) by passing w + r0 (r0 % 4 == 0) */
+  /* output */
+  float* y;
+  int64_t y_bs, y_cs;
+  int32_t Cout, Lout; /* logical output tensor [B, Cout, Lout] */
+  int32_t ncols;      /* conv columns to compute (== Lout except SHUFFLE) */
+  /* prologue */
+  int32_t prologue;
+  float slope;
+  const float* alpha_exp; /* [Cin] exp(alpha)              (ACT1D) */
+  const float* beta_inv;  /* [Cin] 1/(exp(beta)+1e-9)      (ACT1D) */
+  const float* filt;      /* [24]  up filter then down filter (ACT1D) */
+  /* epilogue */
+  int32_t rows, gate_half, up, shuf_pad;
+  const float* bias;
+  const float* cbias;
+  int64_t cbias_bs;
+  int32_t act;
+  const float* mask;
+  int64_t mask_bs;
+  int32_t mask_mode;
+  const float* cscale;
+  int64_t cscale_bs;
+  float scale;
+  const float* res;
+  int64_t res_bs, res_cs;
+  int32_t accumulate;
+  float post_scale;
+} hsp_conv1d_args;
+
+/* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) implicit-GEMM path; stride must be 1,
+ * M % 4 == 0.  `lds_bytes_out`, if non-NULL, receives the dynamic LDS size used. */
+int hsp_conv1d_mfma_f32(const hsp_conv1d_args* a, void* stream);
+/* VALU path: any shape (Cin = 1, Cout = 1, stride > 1, L = 1 "Linear" cases);
+ * rows must be PLAIN; prologue NONE/LRELU/SILU. */
+int hsp_conv1d_direct_f32(const hsp_conv1d_args* a, void* stream);
+/* which tile configuration hsp_conv1d_mfma_f32 would pick: writes BM, BN, KC, LDS bytes */
+int hsp_conv1d_mfma_plan(const hsp_conv1d_args* a, int32_t out4[4]);
+
+/* ------------------------------------------------------- anti-aliased activation */
+/* y = DownSample2x(SnakeBeta(UpSample2x(x))): alias_free_torch/act.py:23-28,
+ * resample.py:25-33,47-49, filter.py:86-95, activations.py:107-119.  x, y contiguous
+ * [B, C, L]; filt = 12 up taps then 12 down taps. */
+int hsp_act1d_snakebeta_f32(const float* x, float* y, int32_t B, int32_t C, int32_t L,
+                            const float* alpha_exp, const float* beta_inv, const float* filt,
+                            void* stream);
+/* per-channel constants of SnakeBeta(alpha_logscale=True): activations.py:113-117 */
+int hsp_snake_consts_f32(const float* alpha_log, const float* beta_log, float* alpha_exp,
+                         float* beta_inv, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------ weight prep */
+/* w[r, :] = g[r] * v[r, :] / ||v[r, :]||_2 : torch.nn.utils.weight_norm (dim 0), recomputed
+ * on every forward by the reference; folded once here. */
+int hsp_fold_weight_norm_f32(const float* v, const float* g, float* w, int32_t rows, int32_t cols,
+                             void* stream);
+/* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (weight re-layout with a host-built index map) */
+int hsp_gather_f32(const float* src, const int32_t* map, float* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------- small ops */
+/* mask[b, t] = t < length[b] : commons.sequence_mask commons.py:128-132 (as float) */
+int hsp_sequence_mask_f32(const int64_t* length, float* mask, int32_t B, int32_t T, void* stream);
+/* y[b, c, t] = x[b, C-1-c, t] : modules.Flip modules.py:270-277 */
+int hsp_flip_channels_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+/* z = (m + noise * exp(logs) * noise_scale) * mask; stats = [B, 2C, T] (m then logs):
+ * hierspeechpp_speechsynthesizer.py:201-202, 687 */
+int hsp_sample_prior_f32(const float* stats, const float* noise, const float* mask, float* z,
+                         int32_t B, int32_t C, int32_t T, float noise_scale, void* stream);
+/* LayerNorm over C (no affine) then optional mask, then x*(1+scale)+shift with per-(b,c)
+ * scale/shift: modules.py:346-347, 396, 398, 409-410.  gamma/beta (per-channel affine,
+ * modules.py:19-31) optional. */
+int hsp_layernorm_mod_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, float eps,
+                          const float* mask, const float* shift, const float* scale, int64_t mod_bs,
+                          const float* gamma, const float* beta, void* stream);
+/* softmax(q^T k * qk_scale [masked]) v per (b, head); q,k,v,o are channel-major
+ * [B, H*D, T] views (strides in elements).  mask, if given, is the key/query validity
+ * [B, T]: scores where mask_q*mask_k == 0 are set to -1e4 (attentions.py:174-175).
+ * Without mask: timm 0.6.13 Attention (modules.py:409).  Optional relative-position
+ * window (emb_rel_k/v [2w+1, D]): attentions.py:165-170,183-186. */
+typedef struct hsp_mha_args {
+  const float *q, *k, *v;
+  float* o;
+  int64_t q_bs, k_bs, v_bs, o_bs; /* batch strides; channel stride is Tq / Tk (contiguous rows) */
+  int32_t B, H, D, Tq, Tk;
+  float qk_scale;
+  const float* mask_q;
+  const float* mask_k; /* [B, Tq], [B, Tk] or NULL */
+  const float* rel_k;
+  const float* rel_v;
+  int32_t window;
+} hsp_mha_args;
+int hsp_mha_f32(const hsp_mha_args* a, void* stream);
+/* out[b, c] = sum_t x[b, c, t] / sum_t mask[b, t] : styleencoder.py:83-91 */
+int hsp_masked_mean_f32(const float* x, const float* mask, float* out, int32_t B, int32_t C,
+                        int32_t T, void* stream);
+/* y[b, c, t] = x[b, c, t] * mask[b, t] : the `x * x_mask` steps (modules.py:407) */
+int hsp_mask_mul_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+/* y = a*x + b*z elementwise (style interpolation, hierspeechpp_speechsynthesizer.py:682) */
+int hsp_axpby_f32(const float* x, const float* z, float* y, float a, float b, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSP_H_ */

@@ -1,0 +1,292 @@
+// HBM-bound pointwise / reduction kernels of the vocoder path (gfx950).
+// Reference call sites are listed next to each entry point in include/hsp.h.
+#include "hsp_device.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t n, int threads, int64_t cap = 1048576) {
+  int64_t b = (n + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------- Activation1d
+// One workgroup = one (b, c) row segment of TILE outputs.  The raw window, the 2x-rate
+// snake signal and the output live in LDS / registers, so HBM sees one read and one
+// write of the tensor (the eager reference makes ~38 passes).
+constexpr int ACT_TILE = 1024;
+constexpr int ACT_THREADS = 256;
+
+__global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                            int L, const float* __restrict__ alpha_exp,
+                                                            const float* __restrict__ beta_inv,
+                                                            const float* __restrict__ filt, int n_tiles) {
+  __shared__ float xr[ACT_TILE + 10];
+  __shared__ float a2[2 * ACT_TILE + 10];
+  const int tile = blockIdx.x % n_tiles;
+  const int row = blockIdx.x / n_tiles;  // b * C + c
+  const int c = row % C;
+  const int p0 = tile * ACT_TILE;
+  const float* xrow = x + (int64_t)row * L;
+  float* yrow = y + (int64_t)row * L;
+  float h[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) h[i] = filt[i];
+  const float ea = alpha_exp[c], binv = beta_inv[c];
+  const int n_out = min(ACT_TILE, L - p0);
+
+  for (int s = threadIdx.x; s < n_out + 10; s += ACT_THREADS) xr[s] = xrow[hsp_clampi(p0 - 5 + s, 0, L - 1)];
+  __syncthreads();
+  const int mlo = 2 * p0 - 5;
+  for (int s = threadIdx.x; s < 2 * n_out + 10; s += ACT_THREADS) {
+    const int m = hsp_clampi(mlo + s, 0, 2 * L - 1);
+    const int q = m >> 1, odd = m & 1;
+    const float* xp = xr + (q - 3 + odd) - (p0 - 5);
+    float u = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) u = fmaf(xp[i], odd ? h[10 - 2 * i] : h[11 - 2 * i], u);
+    a2[s] = hsp_snake(2.0f * u, ea, binv);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < n_out; s += ACT_THREADS) {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v = fmaf(h[12 + k], a2[2 * s + k], v);
+    yrow[p0 + s] = v;
+  }
+}
+
+__global__ void snake_consts_kernel(const float* al, const float* bl, float* ea, float* binv, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) {
+    ea[i] = expf(al[i]);
+    binv[i] = 1.0f / (expf(bl[i]) + 1e-9f);
+  }
+}
+
+// ---------------------------------------------------------------- weight prep
+// one wave per row: ||v_r||_2 by a butterfly reduction, then scale
+__global__ __launch_bounds__(256) void fold_weight_norm_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                               float* __restrict__ w, int rows, int cols) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* vr = v + (int64_t)row * cols;
+  float ss = 0.0f;
+  for (int i = lane; i < cols; i += 64) ss = fmaf(vr[i], vr[i], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float sc = g[row] / sqrtf(ss);
+  float* wr = w + (int64_t)row * cols;
+  for (int i = lane; i < cols; i += 64) wr[i] = vr[i] * sc;
+}
+
+__global__ void gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ map, float* __restrict__ dst,
+                              int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t m = map[i];
+    dst[i] = m >= 0 ? src[m] : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------- small ops
+__global__ void sequence_mask_kernel(const int64_t* length, float* mask, int B, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * T) mask[i] = (i % T) < length[i / T] ? 1.0f : 0.0f;
+}
+
+__global__ void flip_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int T) {
+  const int64_t n = (int64_t)B * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int64_t r = i / T;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    y[i] = x[(b * C + (C - 1 - c)) * T + t];
+  }
+}
+
+__global__ void sample_prior_kernel(const float* __restrict__ stats, const float* __restrict__ noise,
+                                    const float* __restrict__ mask, float* __restrict__ z, int B, int C, int T,
+                                    float noise_scale) {
+  const int64_t n = (int64_t)B * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int64_t r = i / T;
+    const int c = (int)(r % C);
+    const int64_t b = r / C;
+    const float m = stats[(b * 2 * C + c) * T + t];
+    const float logs = stats[(b * 2 * C + C + c) * T + t];
+    z[i] = (m + noise[i] * expf(logs) * noise_scale) * mask[b * T + t];
+  }
+}
+
+__global__ void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
+                                int B, int C, int T) {
+  const int64_t n = (int64_t)B * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int64_t b = i / ((int64_t)C * T);
+    y[i] = x[i] * mask[b * T + t];
+  }
+}
+
+__global__ void axpby_kernel(const float* x, const float* z, float* y, float a, float b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + b * z[i];
+}
+
+// LayerNorm over channels of a (B, C, T) tensor.  Block = 64 time steps x 4 channel
+// groups; lanes run along T (coalesced), the 4 waves split C and combine through LDS.
+// Two passes (mean, then centred variance) like torch's CPU kernel.
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                            int T, float eps, const float* __restrict__ mask,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ scale, int64_t mod_bs,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int n_tt) {
+  __shared__ float red[4][64];
+  const int tt = blockIdx.x % n_tt, b = blockIdx.x / n_tt;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int t = tt * 64 + lane;
+  const bool live = t < T;
+  const float* xb = x + (int64_t)b * C * T;
+  float* yb = y + (int64_t)b * C * T;
+  float s = 0.0f;
+  if (live)
+    for (int c = grp; c < C; c += 4) s += xb[(int64_t)c * T + t];
+  red[grp][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  __syncthreads();
+  float ss = 0.0f;
+  if (live)
+    for (int c = grp; c < C; c += 4) {
+      const float d = xb[(int64_t)c * T + t] - mean;
+      ss = fmaf(d, d, ss);
+    }
+  red[grp][lane] = ss;
+  __syncthreads();
+  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (!live) return;
+  const float mk = mask ? mask[(int64_t)b * T + t] : 1.0f;
+  for (int c = grp; c < C; c += 4) {
+    float v = (xb[(int64_t)c * T + t] - mean) * rstd;
+    if (gamma) v = v * gamma[c] + beta[c];
+    v *= mk;
+    if (scale) v = v * (1.0f + scale[(int64_t)b * mod_bs + c]) + shift[(int64_t)b * mod_bs + c];
+    yb[(int64_t)c * T + t] = v;
+  }
+}
+
+// out[b, c] = sum_t x[b, c, t] / sum_t mask[b, t]; one wave per (b, c)
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                          float* __restrict__ out, int B, int C, int T) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int b = row / C;
+  float s = 0.0f, m = 0.0f;
+  for (int t = lane; t < T; t += 64) {
+    s += x[(int64_t)row * T + t];
+    m += mask[(int64_t)b * T + t];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    m += __shfl_xor(m, o, 64);
+  }
+  if (lane == 0) out[row] = s / m;
+}
+
+}  // namespace
+
+#define HSP_STREAM static_cast<hipStream_t>(stream)
+
+extern "C" int hsp_version(void) { return HSP_VERSION; }
+extern "C" const char* hsp_arch(void) { return "gfx950"; }
+
+extern "C" int hsp_act1d_snakebeta_f32(const float* x, float* y, int32_t B, int32_t C, int32_t L,
+                                       const float* alpha_exp, const float* beta_inv, const float* filt, void* stream) {
+  if (!x || !y || !alpha_exp || !beta_inv || !filt || B <= 0 || C <= 0 || L <= 0) return HSP_EINVAL;
+  const int n_tiles = (L + ACT_TILE - 1) / ACT_TILE;
+  const int64_t blocks = (int64_t)n_tiles * B * C;
+  if (blocks > 0x7fffffff) return HSP_EINVAL;
+  hipLaunchKernelGGL(act1d_kernel, dim3((unsigned)blocks), dim3(ACT_THREADS), 0, HSP_STREAM, x, y, C, L, alpha_exp,
+                     beta_inv, filt, n_tiles);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_snake_consts_f32(const float* al, const float* bl, float* ea, float* binv, int32_t C, void* stream) {
+  if (!al || !bl || !ea || !binv || C <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(snake_consts_kernel, dim3((C + 255) / 256), dim3(256), 0, HSP_STREAM, al, bl, ea, binv, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_fold_weight_norm_f32(const float* v, const float* g, float* w, int32_t rows, int32_t cols,
+                                        void* stream) {
+  if (!v || !g || !w || rows <= 0 || cols <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(fold_weight_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, HSP_STREAM, v, g, w, rows, cols);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_gather_f32(const float* src, const int32_t* map, float* dst, int64_t n, void* stream) {
+  if (!src || !map || !dst || n <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, HSP_STREAM, src, map, dst, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_sequence_mask_f32(const int64_t* length, float* mask, int32_t B, int32_t T, void* stream) {
+  if (!length || !mask || B <= 0 || T <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(sequence_mask_kernel, dim3((B * T + 255) / 256), dim3(256), 0, HSP_STREAM, length, mask, B, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_flip_channels_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, void* stream) {
+  if (!x || !y || x == y || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(flip_channels_kernel, dim3(grid_for((int64_t)B * C * T, 256)), dim3(256), 0, HSP_STREAM, x, y, B,
+                     C, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_sample_prior_f32(const float* stats, const float* noise, const float* mask, float* z, int32_t B,
+                                    int32_t C, int32_t T, float noise_scale, void* stream) {
+  if (!stats || !noise || !mask || !z || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(sample_prior_kernel, dim3(grid_for((int64_t)B * C * T, 256)), dim3(256), 0, HSP_STREAM, stats,
+                     noise, mask, z, B, C, T, noise_scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_mask_mul_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T,
+                                void* stream) {
+  if (!x || !mask || !y || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for((int64_t)B * C * T, 256)), dim3(256), 0, HSP_STREAM, x, mask, y, B,
+                     C, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_axpby_f32(const float* x, const float* z, float* y, float a, float b, int64_t n, void* stream) {
+  if (!x || !z || !y || n <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, HSP_STREAM, x, z, y, a, b, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_layernorm_mod_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, float eps,
+                                     const float* mask, const float* shift, const float* scale, int64_t mod_bs,
+                                     const float* gamma, const float* beta, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
+  if ((shift == nullptr) != (scale == nullptr) || (gamma == nullptr) != (beta == nullptr)) return HSP_EINVAL;
+  const int n_tt = (T + 63) / 64;
+  hipLaunchKernelGGL(layernorm_mod_kernel, dim3((unsigned)(n_tt * B)), dim3(256), 0, HSP_STREAM, x, y, C, T, eps, mask,
+                     shift, scale, mod_bs, gamma, beta, n_tt);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_masked_mean_f32(const float* x, const float* mask, float* out, int32_t B, int32_t C, int32_t T,
+                                   void* stream) {
+  if (!x || !mask || !out || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(masked_mean_kernel, dim3((B * C + 3) / 4), dim3(256), 0, HSP_STREAM, x, mask, out, B, C, T);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,118 @@
+"""Thin Python wrappers (torch tensors in/out) over the pointwise / reduction entry
+points of libhsp.so.  No torch arithmetic happens here: every op is one HIP launch."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _new_like(x):
+    return torch.empty(x.shape, dtype=torch.float32, device=x.device)
+
+
+def _c(x: torch.Tensor) -> torch.Tensor:
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def sequence_mask(length: torch.Tensor, max_length: int) -> torch.Tensor:
+    """commons.sequence_mask (reference commons.py:128-132) as a float mask [B, 1, T]."""
+    length = _c(length.to(torch.int64))
+    B = length.shape[0]
+    mask = torch.empty(B, 1, max_length, dtype=torch.float32, device=length.device)
+    L.check(L.lib().hsp_sequence_mask_f32(L.ptr(length), L.fptr(mask), B, max_length, L.stream_ptr()),
+            "hsp_sequence_mask_f32")
+    return mask
+
+
+def act1d(x, ea, binv, filt, out=None):
+    x = _c(x)
+    B, Cc, T = x.shape
+    out = _new_like(x) if out is None else out
+    L.check(L.lib().hsp_act1d_snakebeta_f32(L.fptr(x), L.fptr(out), B, Cc, T, L.fptr(ea), L.fptr(binv), L.fptr(filt),
+                                            L.stream_ptr()), "hsp_act1d_snakebeta_f32")
+    return out
+
+
+def flip_channels(x):
+    x = _c(x)
+    B, Cc, T = x.shape
+    y = _new_like(x)
+    L.check(L.lib().hsp_flip_channels_f32(L.fptr(x), L.fptr(y), B, Cc, T, L.stream_ptr()), "hsp_flip_channels_f32")
+    return y
+
+
+def sample_prior(stats, noise, mask, noise_scale: float):
+    """z = (m + noise * exp(logs) * noise_scale) * mask; stats = [B, 2C, T]."""
+    stats, noise, mask = _c(stats), _c(noise), _c(mask)
+    B, C2, T = stats.shape
+    z = torch.empty(B, C2 // 2, T, dtype=torch.float32, device=stats.device)
+    assert noise.shape == z.shape, (noise.shape, z.shape)
+    L.check(L.lib().hsp_sample_prior_f32(L.fptr(stats), L.fptr(noise), L.fptr(mask), L.fptr(z), B, C2 // 2, T,
+                                         float(noise_scale), L.stream_ptr()), "hsp_sample_prior_f32")
+    return z
+
+
+def layernorm_mod(x, eps: float, mask=None, shift=None, scale=None, gamma=None, beta=None):
+    """LayerNorm over C of [B, C, T] (+ optional affine), * mask, then * (1 + scale) + shift."""
+    x = _c(x)
+    B, Cc, T = x.shape
+    y = _new_like(x)
+    mod_bs = 0
+    if shift is not None:
+        assert shift.stride(1) == 1 and scale.stride(1) == 1 and shift.stride(0) == scale.stride(0)
+        mod_bs = shift.stride(0)
+    L.check(L.lib().hsp_layernorm_mod_f32(L.fptr(x), L.fptr(y), B, Cc, T, float(eps),
+                                          L.fptr(_c(mask)) if mask is not None else None,
+                                          L.fptr(shift), L.fptr(scale), mod_bs, L.fptr(gamma), L.fptr(beta),
+                                          L.stream_ptr()), "hsp_layernorm_mod_f32")
+    return y
+
+
+def mha(q, k, v, n_heads: int, qk_scale: float, mask_q=None, mask_k=None, rel_k=None, rel_v=None, window=0):
+    """q [B, H*D, Tq], k/v [B, H*D, Tk] (views with contiguous rows) -> [B, H*D, Tq]."""
+    B, HD, Tq = q.shape
+    Tk = k.shape[2]
+    for t_, T_ in ((q, Tq), (k, Tk), (v, Tk)):
+        assert t_.stride(2) == 1 and t_.stride(1) == T_, "attention operands need contiguous [C, T] planes"
+    o = torch.empty(B, HD, Tq, dtype=torch.float32, device=q.device)
+    a = L.MhaArgs()
+    a.q, a.k, a.v, a.o = L.fptr(q), L.fptr(k), L.fptr(v), L.fptr(o)
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    a.B, a.H, a.D, a.Tq, a.Tk = B, n_heads, HD // n_heads, Tq, Tk
+    a.qk_scale = float(qk_scale)
+    if mask_q is not None:
+        a.mask_q, a.mask_k = L.fptr(_c(mask_q)), L.fptr(_c(mask_k))
+    if rel_k is not None:
+        a.rel_k, a.rel_v, a.window = L.fptr(_c(rel_k)), L.fptr(_c(rel_v)), window
+    L.check(L.lib().hsp_mha_f32(C.byref(a), L.stream_ptr()), "hsp_mha_f32")
+    return o
+
+
+def masked_mean(x, mask):
+    x, mask = _c(x), _c(mask)
+    B, Cc, T = x.shape
+    out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    L.check(L.lib().hsp_masked_mean_f32(L.fptr(x), L.fptr(mask), L.fptr(out), B, Cc, T, L.stream_ptr()),
+            "hsp_masked_mean_f32")
+    return out
+
+
+def mask_mul(x, mask):
+    x, mask = _c(x), _c(mask)
+    B, Cc, T = x.shape
+    y = _new_like(x)
+    L.check(L.lib().hsp_mask_mul_f32(L.fptr(x), L.fptr(mask), L.fptr(y), B, Cc, T, L.stream_ptr()), "hsp_mask_mul_f32")
+    return y
+
+
+def axpby(x, z, a: float, b: float):
+    x, z = _c(x), _c(z)
+    assert x.shape == z.shape
+    y = _new_like(x)
+    L.check(L.lib().hsp_axpby_f32(L.fptr(x), L.fptr(z), L.fptr(y), float(a), float(b), x.numel(), L.stream_ptr()),
+            "hsp_axpby_f32")
+    return y

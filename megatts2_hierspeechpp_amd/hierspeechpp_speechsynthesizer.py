@@ -1,0 +1,305 @@
+"""HierSpeech++ synthesizer with the reference's call surface (reference:
+hierspeechpp_speechsynthesizer.py): same class names, constructor arguments, method
+signatures and state-dict keys, so ``inference_plm.py``-style harnesses and reference
+checkpoints work unchanged -- but every tensor op is a launch into libhsp.so.
+
+Typical use::
+
+    net_g = SynthesizerTrn(spec_channels, segment_size, **hps.model)
+    net_g.load_state_dict(checkpoint)        # reference checkpoint or synth weights
+    net_g.finalize("cuda:0")                 # fold weight-norm, pack, upload (once)
+    o, e_ = net_g.infer(mel, w2v, length, f0)
+
+Training-only sub-modules of the reference (``enc_p``, ``enc_q``, ``mel_decoder``,
+discriminators) are not instantiated; their checkpoint keys are skipped on load.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import commons
+from . import functional as Fh
+from . import activations
+from . import modules
+from .alias_free_torch import Activation1d
+from .commons import get_padding
+from .hip_layers import Conv1d, ConvTranspose1d, Linear, finalize as _finalize
+from .styleencoder import StyleEncoder
+
+UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / analysis only
+
+
+class ResidualCouplingBlock_Transformer(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:53-88 (reverse direction)."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers=3, n_flows=4, gin_channels=0):
+        super().__init__()
+        self.channels, self.hidden_channels, self.n_flows = channels, hidden_channels, n_flows
+        # nn.Sequential(Linear, SiLU, Linear): parameters at indices 0 and 2
+        self.cond_block = nn.ModuleList([Linear(gin_channels, 4 * hidden_channels), nn.Identity(),
+                                         Linear(4 * hidden_channels, hidden_channels)])
+        self.flows = nn.ModuleList()
+        for _ in range(n_flows):
+            self.flows.append(modules.ResidualCouplingLayer_Transformer_simple(
+                channels, hidden_channels, kernel_size, dilation_rate, n_layers, mean_only=True))
+            self.flows.append(modules.Flip())
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        if not reverse:
+            raise NotImplementedError("training direction is out of scope")
+        c = self.cond_block[0](g.reshape(g.shape[0], -1), act=L.ACT_SILU)
+        c = self.cond_block[2](c)[:, :, 0]  # [B, hidden]
+        for i in reversed(range(self.n_flows)):
+            x = self.flows[2 * i + 1](x, x_mask, g=c, reverse=True)                 # Flip -> fresh tensor
+            x = self.flows[2 * i](x, x_mask, g=c, reverse=True, inplace=True)      # coupling, in place
+        return x
+
+
+class PosteriorSFEncoder(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:168-203."""
+
+    def __init__(self, src_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                 gin_channels=0):
+        super().__init__()
+        self.out_channels, self.hidden_channels = out_channels, hidden_channels
+        self.pre_source = Conv1d(src_channels, hidden_channels, 1)
+        self.pre_filter = Conv1d(1, hidden_channels, 9, stride=4, padding=4)
+        self.source_enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers // 2, gin_channels=gin_channels)
+        self.filter_enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers // 2, gin_channels=gin_channels)
+        self.enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers // 2, gin_channels=gin_channels)
+        self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
+
+    def stats(self, x_src, x_ftr, x_mask, g=None):
+        x_src = self.pre_source(x_src, mask=x_mask, mask_mode=L.MASK_PRE)
+        x_ftr = self.pre_filter(x_ftr, mask=x_mask, mask_mode=L.MASK_PRE)
+        x_src = self.source_enc(x_src, x_mask, g=g)
+        x_ftr = self.filter_enc(x_ftr, x_mask, g=g)
+        x = self.enc(Fh.axpby(x_src, x_ftr, 1.0, 1.0), x_mask, g=g)
+        return self.proj(x, mask=x_mask, mask_mode=L.MASK_PRE)  # [B, 2*out, T] = (m, logs)
+
+    def forward(self, x_src, x_ftr, x_mask, g=None, noise=None):
+        stats = self.stats(x_src, x_ftr, x_mask, g)
+        C = self.out_channels
+        if noise is None:
+            noise = torch.randn(stats.shape[0], C, stats.shape[2], dtype=torch.float32, device=stats.device)
+        z = Fh.sample_prior(stats, noise, x_mask, 1.0)
+        return z, stats[:, :C], stats[:, C:]
+
+
+class AMPBlock1(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:344-386.  Six launches: each conv carries its
+    Activation1d as prologue; the second conv of every pair adds the residual, and the
+    last one also folds the mean over the parallel blocks of the stage."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5), activation=None):
+        super().__init__()
+        mk = lambda d: Conv1d(channels, channels, kernel_size, dilation=d, padding=get_padding(kernel_size, d),
+                              weight_norm=True)
+        self.convs1 = nn.ModuleList([mk(d) for d in dilation])
+        self.convs2 = nn.ModuleList([mk(1) for _ in dilation])
+        self.num_layers = len(self.convs1) + len(self.convs2)
+        self.activations = nn.ModuleList([
+            Activation1d(activation=activations.SnakeBeta(channels, alpha_logscale=True)) for _ in range(self.num_layers)])
+
+    def forward(self, x, *, out=None, accumulate=False, post_scale=1.0):
+        n = len(self.convs1)
+        for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            last = i == n - 1
+            xt = c1(x, act1d=self.activations[2 * i])
+            x = c2(xt, act1d=self.activations[2 * i + 1], res=x, out=out if last else None,
+                   accumulate=accumulate and last, post_scale=post_scale if last else 1.0)
+        return x
+
+
+def _amp_stage(resblocks, first, num_kernels, x):
+    """xs = sum_j block_j(x); x = xs / num_kernels (hierspeechpp_speechsynthesizer.py:440-446)."""
+    xs = None
+    for j in range(num_kernels):
+        last = j == num_kernels - 1
+        xs = resblocks[first + j](x, out=xs, accumulate=j > 0, post_scale=(1.0 / num_kernels) if last else 1.0)
+    return xs
+
+
+class DBlock(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:317-339.  F.interpolate(nearest, 1/factor) is a
+    strided view of the input (the reference convolves at full rate, then drops 3/4)."""
+
+    def __init__(self, input_size, hidden_size, factor):
+        super().__init__()
+        self.factor = factor
+        self.residual_dense = Conv1d(input_size, hidden_size, 1, weight_norm=True)
+        self.conv = nn.ModuleList([
+            Conv1d(input_size, hidden_size, 3, dilation=1, padding=1, weight_norm=True),
+            Conv1d(hidden_size, hidden_size, 3, dilation=2, padding=2, weight_norm=True),
+            Conv1d(hidden_size, hidden_size, 3, dilation=4, padding=4, weight_norm=True)])
+
+    def forward(self, x):
+        if x.shape[-1] % self.factor != 0:
+            raise L.HspError("DBlock needs a length divisible by its factor (pitch is 4 frames per w2v frame)")
+        xs = x[..., ::self.factor]
+        res = self.residual_dense(xs)
+        h = self.conv[0](xs, lrelu=modules.LRELU_SLOPE)
+        h = self.conv[1](h, lrelu=modules.LRELU_SLOPE)
+        return self.conv[2](h, lrelu=modules.LRELU_SLOPE, res=res)
+
+
+class SourceNetwork(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:251-308."""
+
+    def __init__(self, upsample_initial_channel=256):
+        super().__init__()
+        ks, us, uks = [3, 5, 7], [2, 2], [4, 4]
+        ds = [[1, 3, 5]] * 3
+        self.num_kernels, self.num_upsamples = len(ks), len(us)
+        c0 = upsample_initial_channel
+        self.conv_pre = Conv1d(192, c0, 7, padding=3, weight_norm=True)
+        self.ups = nn.ModuleList([ConvTranspose1d(c0 // 2 ** i, c0 // 2 ** (i + 1), k, u, padding=(k - u) // 2,
+                                                  weight_norm=True) for i, (u, k) in enumerate(zip(us, uks))])
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = c0 // 2 ** (i + 1)
+            for k, d in zip(ks, ds):
+                self.resblocks.append(AMPBlock1(ch, k, d, activation="snakebeta"))
+        self.activation_post = Activation1d(activation=activations.SnakeBeta(ch, alpha_logscale=True))
+        self.conv_post = Conv1d(ch, 1, 7, padding=3, bias=False)
+        self.cond = Conv1d(256, c0, 1)
+
+    def forward(self, x, g):
+        x = self.conv_pre(x, cbias=self.cond(g))
+        for i in range(self.num_upsamples):
+            x = self.ups[i](x)
+            x = _amp_stage(self.resblocks, i * self.num_kernels, self.num_kernels, x)
+        x = self.activation_post(x)
+        return x, self.conv_post(x)
+
+
+class Generator(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:394-451."""
+
+    def __init__(self, initial_channel, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=256):
+        super().__init__()
+        self.num_kernels, self.num_upsamples = len(resblock_kernel_sizes), len(upsample_rates)
+        c0 = upsample_initial_channel
+        self.conv_pre = Conv1d(initial_channel, c0, 7, padding=3, weight_norm=True)
+        self.ups = nn.ModuleList([ConvTranspose1d(c0 // 2 ** i, c0 // 2 ** (i + 1), k, u, padding=(k - u) // 2,
+                                                  weight_norm=True)
+                                  for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes))])
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = c0 // 2 ** (i + 1)
+            for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes):
+                self.resblocks.append(AMPBlock1(ch, k, d, activation="snakebeta"))
+        self.activation_post = Activation1d(activation=activations.SnakeBeta(ch, alpha_logscale=True))
+        self.conv_post = Conv1d(ch, 1, 7, padding=3, bias=False)
+        if gin_channels != 0:
+            self.cond = Conv1d(gin_channels, c0, 1)
+        self.downs = DBlock(c0 // 8, c0, 4)
+        self.proj = Conv1d(c0 // 8, c0 // 2, 7, padding=3)
+
+    def forward(self, x, pitch, g=None):
+        x = self.conv_pre(x, cbias=self.cond(g), res=self.downs(pitch))
+        for i in range(self.num_upsamples):
+            x = self.ups[i](x)
+            if i == 0:
+                x = self.proj(pitch, res=x, out=x)
+            x = _amp_stage(self.resblocks, i * self.num_kernels, self.num_kernels, x)
+        x = self.activation_post(x)
+        return self.conv_post(x, act=L.ACT_TANH)
+
+
+class SynthesizerTrn(nn.Module):
+    """hierspeechpp_speechsynthesizer.py:562-699 (inference methods)."""
+
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_initial_channel, upsample_kernel_sizes, gin_channels=256, prosody_size=20,
+                 uncond_ratio=0., cfg=False, **kwargs):
+        super().__init__()
+        if cfg:
+            raise NotImplementedError("cfg=True (classifier-free null embedding) is not on the reproduced path")
+        self.spec_channels, self.segment_size = spec_channels, segment_size
+        self.inter_channels, self.hidden_channels = inter_channels, hidden_channels
+        self.upsample_rates = upsample_rates
+        self.enc_p_l = PosteriorSFEncoder(1024, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        self.flow_l = ResidualCouplingBlock_Transformer(inter_channels, hidden_channels, 5, 1, 3, gin_channels=gin_channels)
+        self.flow = ResidualCouplingBlock_Transformer(inter_channels, hidden_channels, 5, 1, 3, gin_channels=gin_channels)
+        self.dec = Generator(inter_channels, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                             upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
+        self.sn = SourceNetwork(upsample_initial_channel // 2)
+        self.emb_g = StyleEncoder(in_dim=80, hidden_dim=256, out_dim=gin_channels)
+        self.cfg = cfg
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts the reference's checkpoints: bare state dict (inference_plm.py:218) or
+        {'model': ...} (utils.py:19-44); keys of training-only sub-modules are skipped."""
+        if "model" in state_dict and not any(k.startswith("dec.") for k in state_dict):
+            state_dict = state_dict["model"]
+        sd = {k: v for k, v in state_dict.items() if not k.startswith(UNUSED_PREFIXES)}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def finalize(self, device, materialize: bool = True):
+        """Fold weight-norm and pack all weights into one device arena (call once after
+        loading weights; again after changing them)."""
+        return _finalize(self, device, materialize)
+
+    # ---------------------------------------------------------------- inference
+    def _prior(self, w2v, f0, y_mask, g, noise, noise_scale):
+        stats = self.enc_p_l.stats(w2v, f0, y_mask, g)
+        C = self.inter_channels
+        if noise is None:
+            noise = torch.randn(stats.shape[0], C, stats.shape[2], dtype=torch.float32, device=stats.device)
+        return Fh.sample_prior(stats, noise, y_mask, noise_scale)
+
+    def _decode(self, z, y_mask, g):
+        z = self.flow_l(z, y_mask, g=g, reverse=True)
+        z = self.flow(z, y_mask, g=g, reverse=True)
+        e, e_ = self.sn(z, g)
+        return self.dec(z, e, g=g), e_
+
+    @torch.no_grad()
+    def infer(self, x_mel, w2v, length, f0, noise: Optional[torch.Tensor] = None):
+        """:635-651 -> (o [B,1,320T], e_ [B,1,4T]).  ``noise`` ([B,192,T]) replaces the
+        randn_like draw of :202 for reproducible parity runs."""
+        x_mask = commons.sequence_mask(length, x_mel.size(2))
+        g = self.emb_g(x_mel, x_mask).unsqueeze(-1)
+        z = self._prior(w2v, f0, x_mask, g, noise, 1.0)
+        return self._decode(z, x_mask, g)
+
+    @torch.no_grad()
+    def voice_conversion(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333, uncond=False,
+                         noise: Optional[torch.Tensor] = None):
+        """:652-673."""
+        if uncond:
+            raise NotImplementedError("uncond needs cfg=True")
+        trg_mask = commons.sequence_mask(trg_length, trg_mel.size(2))
+        g = self.emb_g(trg_mel, trg_mask).unsqueeze(-1)
+        y_mask = commons.sequence_mask(src_length, src.size(2))
+        z = self._prior(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
+        return self._decode(z, y_mask, g)[0]
+
+    @torch.no_grad()
+    def voice_conversion_noise_control(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333,
+                                       uncond=False, denoise_ratio=0, noise: Optional[torch.Tensor] = None):
+        """:674-699.  trg_mel holds two prompts (original, denoised); their style vectors
+        are interpolated with ``denoise_ratio`` (B = 1 by construction)."""
+        if uncond:
+            raise NotImplementedError("uncond needs cfg=True")
+        trg_mask = commons.sequence_mask(trg_length, trg_mel.size(2))
+        g = self.emb_g(trg_mel, trg_mask)  # [2, 256]
+        g = Fh.axpby(g[:1], g[1:], 1.0 - denoise_ratio, float(denoise_ratio)).unsqueeze(-1)
+        y_mask = commons.sequence_mask(src_length, src.size(2))
+        z = self._prior(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
+        return self._decode(z, y_mask, g)[0]
+
+
+def _f0_3d(f0):
+    """inference_plm.py:172 passes f0 as [1, 4T]; torch treats that as an unbatched
+    (C=1, L) input of Conv1d."""
+    return f0.unsqueeze(0) if f0.dim() == 2 else f0

@@ -1,0 +1,326 @@
+"""Host-side layer objects over the libhsp C ABI.
+
+``Conv1d`` / ``ConvTranspose1d`` / ``Linear`` keep the reference's parameter names
+(``weight`` or ``weight_g``/``weight_v``, ``bias``) so reference checkpoints load
+unchanged, and own a *packed* copy of the weight-norm-folded weights in the layout
+the kernels read (``w[K][Cin][M]``).  Packing runs once on the GPU
+(``hsp_fold_weight_norm_f32`` + ``hsp_gather_f32`` with a host-built index map); the
+reference instead re-derives ``g*v/||v||`` on every forward.
+
+All packed tensors of a model live in one contiguous fp32 arena so that a multi-GPU
+job can ship them with a single RCCL broadcast.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .synth import kaiser_sinc_filter12
+
+
+# ------------------------------------------------------------------ index maps (host logic)
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def plain_rows(cout: int) -> np.ndarray:
+    """packed row -> source output channel (-1 = zero padding); M multiple of 4."""
+    m = _round_up(cout, 4)
+    rows = np.full(m, -1, np.int64)
+    rows[:cout] = np.arange(cout)
+    return rows
+
+
+def gated_rows(half: int) -> np.ndarray:
+    """Row order of the GATE modes: 32-row blocks alternate between the 'a' half
+    (tanh / linear) and the matching 'b' half (sigmoid) so that one wave holds both
+    accumulators of an output channel (hsp_conv1d_mfma.hip epilogue)."""
+    assert half % 32 == 0, "gated convs need a half-width that is a multiple of 32"
+    m = np.arange(2 * half)
+    return ((m >> 5) & 1) * half + (m >> 6) * 32 + (m & 31)
+
+
+def conv_pack_map(cout: int, cin: int, k: int, rows: np.ndarray) -> np.ndarray:
+    """index map src[Cout, Cin, K] -> dst[K][Cin][M]."""
+    M = rows.shape[0]
+    j = np.arange(k)[:, None, None]
+    ci = np.arange(cin)[None, :, None]
+    co = rows[None, None, :]
+    idx = (co * cin + ci) * k + j
+    idx = np.where(co >= 0, idx, -1)
+    return np.ascontiguousarray(np.broadcast_to(idx, (k, cin, M))).astype(np.int32).reshape(-1)
+
+
+def convtr_pack_map(cin: int, cout: int, k: int, up: int) -> Tuple[np.ndarray, int, int]:
+    """ConvTranspose1d(stride=up) as a polyphase conv: returns (map, K', M).
+
+    y[co, n] = sum_ci sum_i x[ci, i] * w[ci, co, n + p - up*i]; writing n + p = up*q + r
+    gives, for packed row m = co*up + r and tap j' (input index q + j' - (K'-1)),
+    the source tap r + (K'-1-j')*up (absent taps are zero).  src is w[Cin, Cout, K]."""
+    kp = -(-k // up)
+    M = _round_up(cout * up, 4)
+    m = np.arange(M)
+    co, r = m // up, m % up
+    jp = np.arange(kp)[:, None, None]
+    ci = np.arange(cin)[None, :, None]
+    tap = r[None, None, :] + (kp - 1 - jp) * up
+    idx = (ci * cout + co[None, None, :]) * k + tap
+    ok = (tap < k) & (co[None, None, :] < cout)
+    return np.where(ok, idx, -1).astype(np.int32).reshape(-1), kp, M
+
+
+# ---------------------------------------------------------------------------- arena
+class WeightArena:
+    """One contiguous fp32 device buffer holding every packed tensor of a model."""
+
+    ALIGN = 64  # floats (256 B): keeps float4 weight loads aligned
+
+    def __init__(self):
+        self.specs: List[Tuple[object, str, int]] = []
+        self.buffer: Optional[torch.Tensor] = None
+        self.views: Dict[Tuple[int, str], torch.Tensor] = {}
+        self._offsets: List[int] = []
+        self.total = 0
+
+    def request(self, owner, name: str, numel: int):
+        self._offsets.append(self.total)
+        self.specs.append((owner, name, numel))
+        self.total += _round_up(numel, self.ALIGN)
+
+    def allocate(self, device):
+        self.buffer = torch.zeros(max(self.total, 1), dtype=torch.float32, device=device)
+        for (owner, name, numel), off in zip(self.specs, self._offsets):
+            self.views[(id(owner), name)] = self.buffer[off:off + numel]
+
+    def view(self, owner, name: str) -> torch.Tensor:
+        return self.views[(id(owner), name)]
+
+
+class HipLayer(nn.Module):
+    """Base of modules that own packed device state."""
+
+    def hsp_requests(self) -> List[Tuple[str, int]]:
+        return []
+
+    def hsp_fill(self, arena: WeightArena, materialize: bool) -> None:
+        pass
+
+
+def _gather(src: torch.Tensor, idx_map: np.ndarray, dst: torch.Tensor):
+    mp = torch.from_numpy(idx_map).to(src.device)
+    L.check(L.lib().hsp_gather_f32(L.fptr(src), L.ptr(mp), L.fptr(dst), dst.numel(), L.stream_ptr()), "hsp_gather_f32")
+    # `mp` must outlive the asynchronous gather on the current stream
+    torch.cuda.current_stream().synchronize()
+
+
+def _fold(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    rows = v.shape[0]
+    cols = v.numel() // rows
+    w = torch.empty_like(v)
+    L.check(L.lib().hsp_fold_weight_norm_f32(L.fptr(v.contiguous()), L.fptr(g.contiguous()), L.fptr(w), rows, cols,
+                                             L.stream_ptr()), "hsp_fold_weight_norm_f32")
+    return w
+
+
+class _ConvBase(HipLayer):
+    def __init__(self, weight_shape, rows0: int, bias: bool, weight_norm: bool):
+        super().__init__()
+        if weight_norm:
+            self.weight_g = nn.Parameter(torch.ones(rows0, 1, 1), requires_grad=False)
+            self.weight_v = nn.Parameter(torch.zeros(*weight_shape), requires_grad=False)
+        else:
+            self.weight = nn.Parameter(torch.zeros(*weight_shape), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(bias), requires_grad=False) if bias else None
+        self.wn = weight_norm
+        self._w: Optional[torch.Tensor] = None
+        self._b: Optional[torch.Tensor] = None
+
+    def _folded(self) -> torch.Tensor:
+        if self.wn:
+            return _fold(self.weight_v.data, self.weight_g.data)
+        return self.weight.data.contiguous()
+
+    def _require_ready(self):
+        if self._w is None:
+            raise L.HspError(f"{type(self).__name__} used before finalize(): call model.finalize(device) after "
+                             "loading weights")
+
+
+class Conv1d(_ConvBase):
+    """torch.nn.Conv1d (optionally weight-normed) with fused prologue/epilogue."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=True, weight_norm=False,
+                 rows=L.ROWS_PLAIN, weight_2d=False):
+        super().__init__((cout, cin) if weight_2d else (cout, cin, k), cout, cout if bias else 0, weight_norm)
+        self.cin, self.cout, self.k, self.stride, self.padding, self.dilation = cin, cout, k, stride, padding, dilation
+        self.rows = rows
+        if rows in (L.ROWS_GATE_WN, L.ROWS_GATE_GLU):
+            self.row_map = gated_rows(cout // 2)
+        else:
+            self.row_map = plain_rows(cout)
+        self.M = int(self.row_map.shape[0])
+
+    def hsp_requests(self):
+        return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.bias is not None else [])
+
+    def hsp_fill(self, arena, materialize):
+        self._w = arena.view(self, "w")
+        self._b = arena.view(self, "b") if self.bias is not None else None
+        if materialize:
+            _gather(self._folded(), conv_pack_map(self.cout, self.cin, self.k, self.row_map), self._w)
+            if self._b is not None:
+                self._b.copy_(self.bias.data)
+
+    # ----------------------------------------------------------------------------
+    def forward(self, x, *, act1d=None, lrelu: Optional[float] = None, silu_in=False, act=L.ACT_NONE, cbias=None,
+                mask=None, mask_mode=L.MASK_NONE, cscale=None, scale=1.0, res=None, out=None, accumulate=False,
+                post_scale=1.0, force_direct=False, row_range=None):
+        """``row_range=(r0, r1)`` computes only output channels [r0, r1) (PLAIN rows, r0 % 4 == 0):
+        the WN res/skip layer is one parameter set feeding two differently-fused launches."""
+        self._require_ready()
+        B, Cin, Lin = x.shape
+        assert Cin == self.cin, (Cin, self.cin)
+        gated = self.rows in (L.ROWS_GATE_WN, L.ROWS_GATE_GLU)
+        cout = self.cout // 2 if gated else self.cout
+        r0 = 0
+        if row_range is not None:
+            r0, r1 = row_range
+            assert not gated and r0 % 4 == 0 and 0 <= r0 < r1 <= self.cout
+            cout = r1 - r0
+        Lout = (Lin + 2 * self.padding - self.dilation * (self.k - 1) - 1) // self.stride + 1
+        if out is None:
+            out = torch.empty(B, cout, Lout, dtype=torch.float32, device=x.device)
+        a = L.Conv1dArgs()
+        a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(x), x.stride(0), x.stride(1), x.stride(2)
+        a.B, a.Cin, a.Lin = B, Cin, Lin
+        a.w, a.K, a.dil, a.pad, a.stride = L.fptr(self._w) + 4 * r0, self.k, self.dilation, self.padding, self.stride
+        a.M = self.M if row_range is None else _round_up(cout, 4)
+        a.w_ld = self.M
+        _set_out(a, out, B, cout, Lout)
+        a.ncols = Lout
+        a.rows, a.gate_half = self.rows, (cout if gated else 0)
+        a.bias = (L.fptr(self._b) + 4 * r0) if self._b is not None else None
+        _set_epilogue(a, act, cbias, mask, mask_mode, cscale, scale, res, accumulate, post_scale, out)
+        if act1d is not None:
+            a.prologue = L.PRO_ACT1D
+            a.alpha_exp, a.beta_inv, a.filt = L.fptr(act1d._ea), L.fptr(act1d._binv), L.fptr(act1d._filt)
+        elif lrelu is not None:
+            a.prologue, a.slope = L.PRO_LRELU, float(lrelu)
+        elif silu_in:
+            a.prologue = L.PRO_SILU
+        direct = (force_direct or self.stride != 1 or self.cin < 8 or cout < 8 or Lout < 8 or silu_in) \
+            and not gated and act1d is None
+        if direct:
+            L.check(L.lib().hsp_conv1d_direct_f32(C.byref(a), L.stream_ptr()), "hsp_conv1d_direct_f32")
+        else:
+            L.check(L.lib().hsp_conv1d_mfma_f32(C.byref(a), L.stream_ptr()), "hsp_conv1d_mfma_f32")
+        return out
+
+
+class ConvTranspose1d(_ConvBase):
+    """torch.nn.ConvTranspose1d (weight-normed) as a polyphase conv on the MFMA kernel."""
+
+    def __init__(self, cin, cout, k, stride, padding=0, bias=True, weight_norm=False):
+        super().__init__((cin, cout, k), cin, cout if bias else 0, weight_norm)
+        self.cin, self.cout, self.k, self.up, self.padding = cin, cout, k, stride, padding
+        self.pack_map, self.kp, self.M = convtr_pack_map(cin, cout, k, stride)
+
+    def hsp_requests(self):
+        return [("w", self.kp * self.cin * self.M)] + ([("b", self.cout)] if self.bias is not None else [])
+
+    def hsp_fill(self, arena, materialize):
+        self._w = arena.view(self, "w")
+        self._b = arena.view(self, "b") if self.bias is not None else None
+        if materialize:
+            _gather(self._folded(), self.pack_map, self._w)
+            if self._b is not None:
+                self._b.copy_(self.bias.data)
+
+    def forward(self, x, *, res=None, out=None):
+        self._require_ready()
+        B, Cin, Lin = x.shape
+        assert Cin == self.cin
+        Lout = (Lin - 1) * self.up - 2 * self.padding + self.k
+        if out is None:
+            out = torch.empty(B, self.cout, Lout, dtype=torch.float32, device=x.device)
+        a = L.Conv1dArgs()
+        a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(x), x.stride(0), x.stride(1), x.stride(2)
+        a.B, a.Cin, a.Lin = B, Cin, Lin
+        a.w, a.K, a.M, a.dil, a.pad, a.stride = L.fptr(self._w), self.kp, self.M, 1, self.kp - 1, 1
+        a.w_ld = self.M
+        _set_out(a, out, B, self.cout, Lout)
+        a.ncols = (Lout - 1 + self.padding) // self.up + 1
+        a.rows, a.up, a.shuf_pad = L.ROWS_SHUFFLE, self.up, self.padding
+        a.bias = L.fptr(self._b)
+        _set_epilogue(a, L.ACT_NONE, None, None, L.MASK_NONE, None, 1.0, res, False, 1.0, out)
+        L.check(L.lib().hsp_conv1d_mfma_f32(C.byref(a), L.stream_ptr()), "hsp_conv1d_mfma_f32")
+        return out
+
+
+class Linear(Conv1d):
+    """torch.nn.Linear on a (B, C) or (B, C, 1) style vector == 1x1 conv with L = 1.
+    Parameters keep nn.Linear's 2-D ``weight`` shape for checkpoint compatibility."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__(cin, cout, 1, bias=bias, weight_2d=True)
+
+    def forward(self, x, **kw):
+        x3 = x.reshape(x.shape[0], self.cin, 1)
+        return super().forward(x3, force_direct=True, **kw)
+
+
+def _set_out(a, out, B, cout, Lout):
+    assert out.shape == (B, cout, Lout), (tuple(out.shape), (B, cout, Lout))
+    assert out.stride(2) == 1 or Lout == 1
+    a.y, a.y_bs, a.y_cs = L.fptr(out), out.stride(0), out.stride(1)
+    a.Cout, a.Lout = cout, Lout
+
+
+def _set_epilogue(a, act, cbias, mask, mask_mode, cscale, scale, res, accumulate, post_scale, out):
+    a.act = act
+    if cbias is not None:
+        assert cbias.dim() >= 2 and cbias.stride(1) == 1
+        a.cbias, a.cbias_bs = L.fptr(cbias), cbias.stride(0)
+    if mask is not None and mask_mode != L.MASK_NONE:
+        assert mask.stride(-1) == 1
+        a.mask, a.mask_bs, a.mask_mode = L.fptr(mask), mask.stride(0), mask_mode
+    if cscale is not None:
+        assert cscale.stride(1) == 1
+        a.cscale, a.cscale_bs = L.fptr(cscale), cscale.stride(0)
+    a.scale = float(scale)
+    if res is not None:
+        assert res.shape == out.shape and (res.stride(2) == 1 or res.shape[2] == 1)
+        a.res, a.res_bs, a.res_cs = L.fptr(res), res.stride(0), res.stride(1)
+    a.accumulate = 1 if accumulate else 0
+    a.post_scale = float(post_scale)
+
+
+# ------------------------------------------------------------------ finalisation
+def finalize(model: nn.Module, device, materialize: bool = True) -> WeightArena:
+    """Pack every HipLayer of ``model`` into one arena on ``device``.
+
+    ``materialize=False`` only lays the arena out (same offsets on every rank) so that
+    the contents can arrive by broadcast (parallel.broadcast_weights)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise L.HspError("finalize() needs a ROCm device: the product path has no CPU fallback")
+    L.lib()
+    if materialize:
+        model.to(device)
+    arena = WeightArena()
+    layers = [m for m in model.modules() if isinstance(m, HipLayer)]
+    for m in layers:
+        for name, numel in m.hsp_requests():
+            arena.request(m, name, numel)
+    with torch.cuda.device(device):
+        arena.allocate(device)
+        for m in layers:
+            m.hsp_fill(arena, materialize)
+        torch.cuda.current_stream().synchronize()
+    model._hsp_arena = arena
+    return arena

@@ -1,0 +1,144 @@
+"""WN, DiT-style coupling layers and Flip with the reference's class names, constructor
+arguments and state-dict keys (reference: modules.py).  Every tensor stays channel-major
+(B, C, T); the reference's transposes to (B, T, C) around the DiT blocks are layout
+changes only.  All arithmetic is in libhsp.so."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import functional as Fh
+from .hip_layers import Conv1d, Linear
+
+LRELU_SLOPE = 0.1  # modules.py:17
+
+
+class WN(nn.Module):
+    """modules.WN (modules.py:111-176).  Per layer: one gated in-conv launch (conv k +
+    conditioning bias + tanh*sigmoid in the epilogue) and two 1x1 launches over the row
+    halves of res_skip (residual update of x, accumulation of the skip output)."""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        assert hidden_channels % 32 == 0, "gated MFMA epilogue needs hidden_channels % 32 == 0"
+        self.hidden_channels, self.kernel_size = hidden_channels, kernel_size
+        self.dilation_rate, self.n_layers, self.gin_channels = dilation_rate, n_layers, gin_channels
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        if gin_channels != 0:
+            self.cond_layer = Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1, weight_norm=True)
+        for i in range(n_layers):
+            d = dilation_rate ** i
+            self.in_layers.append(Conv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=d,
+                                         padding=int((kernel_size * d - d) / 2), weight_norm=True,
+                                         rows=L.ROWS_GATE_WN))
+            rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(Conv1d(hidden_channels, rs, 1, weight_norm=True))
+
+    def forward(self, x, x_mask, g=None, **kwargs):
+        H = self.hidden_channels
+        gc = self.cond_layer(g) if g is not None else None  # [B, 2H*n, 1]
+        out = None
+        for i in range(self.n_layers):
+            cb = gc[:, 2 * H * i: 2 * H * (i + 1)] if gc is not None else None
+            acts = self.in_layers[i](x, cbias=cb)
+            if i < self.n_layers - 1:
+                x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
+                out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
+                x = x_new
+            else:
+                # last layer: output = (output + rs) * x_mask   (modules.py:175-176)
+                out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None, mask=x_mask,
+                                              mask_mode=L.MASK_NONE)
+        return Fh.mask_mul(out, x_mask)
+
+
+class Flip(nn.Module):
+    """modules.Flip (modules.py:270-277)."""
+
+    def forward(self, x, *args, reverse=False, **kwargs):
+        y = Fh.flip_channels(x)
+        if not reverse:
+            raise NotImplementedError("training direction (logdet) is out of scope")
+        return y
+
+
+class Attention(nn.Module):
+    """timm==0.6.13 vision_transformer.Attention (third party; imported at modules.py:13)
+    on channel-major tensors: qkv / proj keep nn.Linear's 2-D weights."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = Conv1d(dim, dim * 3, 1, bias=qkv_bias, weight_2d=True)
+        self.proj = Conv1d(dim, dim, 1, weight_2d=True)
+
+
+class FFN_Conv(nn.Module):
+    """modules.FFN_Conv (modules.py:357-388)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, kernel=5, p_dropout=0.1, **_):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = Conv1d(in_features, hidden_features, kernel, padding=(kernel - 1) // 2)
+        self.fc2 = Conv1d(hidden_features, out_features, 1)
+
+
+class DiTConVBlock(nn.Module):
+    """modules.DiTConVBlock (modules.py:390-411).  x [B, C, T], c [B, C], x_mask [B, 1, T]
+    (the reference passes x as [B, T, C] and x_mask as [B, T, 1]; same values)."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, kernel=9, p_dropout=0.1, **block_kwargs):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True)
+        self.mlp = FFN_Conv(hidden_size, int(hidden_size * mlp_ratio), kernel=kernel, p_dropout=p_dropout)
+        # nn.Sequential(SiLU, Linear) in the reference: index 1 carries the parameters
+        self.adaLN_modulation = nn.ModuleList([nn.Identity(), Linear(hidden_size, 6 * hidden_size)])
+
+    def forward(self, x, c, x_mask):
+        C = self.hidden_size
+        x = Fh.mask_mul(x, x_mask)
+        mod = self.adaLN_modulation[1](c, silu_in=True)  # [B, 6C, 1]
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = (mod[:, i * C:(i + 1) * C, 0] for i in range(6))
+        h = Fh.layernorm_mod(x, 1e-6, mask=x_mask, shift=sh_a, scale=sc_a)
+        qkv = self.attn.qkv(h)
+        o = Fh.mha(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale)
+        x = self.attn.proj(o, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_a, res=x)
+        h = Fh.layernorm_mod(x, 1e-6, shift=sh_m, scale=sc_m)
+        y = self.mlp.fc1(h, act=L.ACT_GELU_TANH)
+        # fc2(y * mask) * mask == (W y + b) * mask for a 1x1 conv and a 0/1 mask
+        return self.mlp.fc2(y, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_m, res=x)
+
+
+class ResidualCouplingLayer_Transformer_simple(nn.Module):
+    """modules.ResidualCouplingLayer_Transformer_simple (modules.py:413-488), reverse
+    direction, mean_only."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0.1,
+                 mean_only=False):
+        super().__init__()
+        assert channels % 2 == 0, "channels should be divisible by 2"
+        if not mean_only:
+            raise NotImplementedError("only mean_only=True couplings exist on the hot path")
+        self.channels, self.hidden_channels, self.half_channels = channels, hidden_channels, channels // 2
+        self.pre = Conv1d(self.half_channels, hidden_channels, 1)
+        self.enc_block = nn.ModuleList([DiTConVBlock(hidden_channels, 2, mlp_ratio=4.0, kernel=5, p_dropout=p_dropout)
+                                        for _ in range(n_layers)])
+        self.post = Conv1d(hidden_channels, self.half_channels, 1)
+
+    def forward(self, x, x_mask, g=None, reverse=False, inplace=False):
+        if not reverse:
+            raise NotImplementedError("training direction (logdet) is out of scope")
+        half = self.half_channels
+        h = self.pre(x[:, :half], mask=x_mask, mask_mode=L.MASK_PRE)
+        for blk in self.enc_block:
+            h = blk(h, g, x_mask)
+        out = x if inplace else x.clone()
+        # x1 <- (x1 - post(h) * mask) * mask          (modules.py:473,486)
+        self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, half:], out=out[:, half:])
+        return out

@@ -1,0 +1,186 @@
+"""Shared test plumbing: golden-fixture loading and the fixture-kind -> module mapping.
+
+Golden fixtures (tests/golden/*.npz) hold outputs of the REFERENCE run on CPU by
+tools/make_golden.py; weights are regenerated from the synthetic recipe."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from megatts2_hierspeechpp_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# fp32 parity bar of BASELINE.json:north_star: 1e-4 on outputs of O(1) magnitude;
+# scaled by the reference's peak magnitude for outputs that are not audio
+ATOL = 1e-4
+
+
+def fixture_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    arrays = {k: z[k] for k in z.files if k != "meta"}
+    return meta, arrays
+
+
+def synth_sd(meta, as_torch=True):
+    pre = meta["prefix"] + "." if meta["prefix"] else ""
+    sd = {k: synth.synth_tensor(pre + k, tuple(s), meta["seed"]) for k, s in meta["shapes"]}
+    return {k: torch.from_numpy(v) for k, v in sd.items()} if as_torch else sd
+
+
+def oracle_sd(meta):
+    """state dict keyed the way oracle functions address it (prefix.key)."""
+    pre = meta["prefix"] + "." if meta["prefix"] else ""
+    return {pre + k: v for k, v in synth_sd(meta).items()}
+
+
+def tol_for(ref: np.ndarray) -> float:
+    return ATOL * max(1.0, float(np.abs(ref).max()))
+
+
+def outputs(arrays):
+    return [arrays[k] for k in sorted(k for k in arrays if k.startswith("out"))]
+
+
+# ------------------------------------------------------------------ oracle side
+def run_oracle(meta, arrays):
+    from oracle import hsp_oracle as O
+    sd = oracle_sd(meta)
+    t = lambda k: torch.from_numpy(arrays[k])
+    kind, name = meta["kind"], meta["prefix"]
+    cfg = O.default_config()
+    mask = None
+    if "lengths" in arrays:
+        T = {"dit_block": lambda: arrays["x"].shape[1], "style_encoder": lambda: arrays["mel"].shape[2],
+             "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2]}.get(
+            kind, lambda: arrays["x"].shape[2])()
+        mask = O.sequence_mask(t("lengths"), T).unsqueeze(1).float()
+    if kind == "act1d":
+        return [O.act1d(sd, name, t("x"))]
+    if kind == "amp_block":
+        return [O.amp_block(sd, name, t("x"), meta["k"])]
+    if kind == "convtr":
+        return [O.conv_transpose1d(sd, name, t("x"), meta["u"], (meta["k"] - meta["u"]) // 2)]
+    if kind == "dblock":
+        return [O.dblock(sd, name, t("x"))]
+    if kind == "wn":
+        return [O.wavenet(sd, name, t("x"), mask, t("g"), meta["hidden"], meta["k"], meta["n_layers"])]
+    if kind == "dit_block":
+        return [O.dit_conv_block(sd, name, t("x"), t("c"), mask.transpose(1, 2))]
+    if kind == "coupling":
+        return [O.coupling_reverse(sd, name, t("x"), mask, t("c"))]
+    if kind == "flow":
+        return [O.flow_reverse(sd, name, t("x"), mask, t("g"))]
+    if kind == "style_encoder":
+        return [O.style_encoder(sd, name, t("mel"), mask)]
+    if kind == "posterior_sf":
+        return list(O.posterior_sf_encoder(sd, name, t("w2v"), t("f0"), mask, t("g"), t("noise")))
+    if kind == "source_network":
+        return list(O.source_network(sd, name, t("z"), t("g")))
+    if kind == "generator":
+        return [O.generator(sd, name, t("z"), t("e"), t("g"), cfg)]
+    if kind == "infer":
+        return list(O.synth_infer(sd, cfg, t("mel"), t("w2v"), t("lengths"), t("f0"), t("noise")))
+    if kind == "vc":
+        return [O.synth_voice_conversion_noise_control(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"),
+                                                       t("f0"), meta["noise_scale"], meta["denoise_ratio"], t("noise"))]
+    if kind == "speechsr":
+        return [O.speechsr(sd, t("x"), meta["factor"], name + ".dec")]
+    raise KeyError(kind)
+
+
+# --------------------------------------------------------------------- HIP side
+def build_module(meta):
+    """The product-side module matching a fixture kind (CPU construction only)."""
+    from oracle.hsp_oracle import default_config
+    from megatts2_hierspeechpp_amd import activations, modules
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as H
+    from megatts2_hierspeechpp_amd.alias_free_torch import Activation1d
+    from megatts2_hierspeechpp_amd.hip_layers import ConvTranspose1d
+    from megatts2_hierspeechpp_amd.styleencoder import StyleEncoder
+    kind = meta["kind"]
+    cfg = default_config()
+    shapes = dict((k, tuple(s)) for k, s in meta["shapes"])
+    if kind == "act1d":
+        return Activation1d(activations.SnakeBeta(shapes["act.alpha"][0], alpha_logscale=True))
+    if kind == "amp_block":
+        return H.AMPBlock1(meta["C"], meta["k"], (1, 3, 5))
+    if kind == "convtr":
+        return ConvTranspose1d(meta["ci"], meta["co"], meta["k"], meta["u"], padding=(meta["k"] - meta["u"]) // 2,
+                               weight_norm=True)
+    if kind == "dblock":
+        return H.DBlock(16, 64, 4)
+    if kind == "wn":
+        return modules.WN(meta["hidden"], meta["k"], 1, meta["n_layers"], gin_channels=256)
+    if kind == "dit_block":
+        return modules.DiTConVBlock(192, 2, mlp_ratio=4.0, kernel=5)
+    if kind == "coupling":
+        return modules.ResidualCouplingLayer_Transformer_simple(192, 192, 5, 1, 3, mean_only=True)
+    if kind == "flow":
+        return H.ResidualCouplingBlock_Transformer(192, 192, 5, 1, 3, gin_channels=256)
+    if kind == "style_encoder":
+        return StyleEncoder(in_dim=80, hidden_dim=256, out_dim=256)
+    if kind == "posterior_sf":
+        return H.PosteriorSFEncoder(1024, 192, 192, 5, 1, 16, gin_channels=256)
+    if kind == "source_network":
+        return H.SourceNetwork(512)
+    if kind == "generator":
+        return H.Generator(192, cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"], cfg["upsample_rates"],
+                           cfg["upsample_initial_channel"], cfg["upsample_kernel_sizes"], gin_channels=256)
+    if kind in ("infer", "vc"):
+        return H.SynthesizerTrn(641, 61440 // 320, **cfg)
+    raise KeyError(kind)
+
+
+def run_hip(meta, arrays, device):
+    """Run a fixture through the HIP product path; returns a list of numpy outputs."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    mod = build_module(meta)
+    mod.load_state_dict(synth_sd(meta), strict=True)
+    finalize(mod, device)
+    d = lambda k: torch.from_numpy(arrays[k]).to(device)
+    kind = meta["kind"]
+    mask = None
+    if "lengths" in arrays:
+        T = {"dit_block": lambda: arrays["x"].shape[1], "style_encoder": lambda: arrays["mel"].shape[2],
+             "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2]}.get(
+            kind, lambda: arrays["x"].shape[2])()
+        mask = Fh.sequence_mask(d("lengths"), T)
+    with torch.no_grad():
+        if kind in ("act1d", "amp_block", "convtr", "dblock"):
+            out = [mod(d("x"))]
+        elif kind == "wn":
+            out = [mod(d("x"), mask, g=d("g"))]
+        elif kind == "dit_block":
+            out = [mod(d("x").transpose(1, 2).contiguous(), d("c"), mask).transpose(1, 2)]
+        elif kind == "coupling":
+            out = [mod(d("x"), mask, g=d("c"), reverse=True)]
+        elif kind == "flow":
+            out = [mod(d("x"), mask, g=d("g"), reverse=True)]
+        elif kind == "style_encoder":
+            out = [mod(d("mel"), mask)]
+        elif kind == "posterior_sf":
+            out = list(mod(d("w2v"), d("f0"), mask, g=d("g"), noise=d("noise")))
+        elif kind == "source_network":
+            out = list(mod(d("z"), d("g")))
+        elif kind == "generator":
+            out = [mod(d("z"), d("e"), g=d("g"))]
+        elif kind == "infer":
+            out = list(mod.infer(d("mel"), d("w2v"), d("lengths"), d("f0"), noise=d("noise")))
+        elif kind == "vc":
+            out = [mod.voice_conversion_noise_control(d("w2v"), d("src_length"), d("mel"), d("trg_length"), d("f0"),
+                                                      noise_scale=meta["noise_scale"],
+                                                      denoise_ratio=meta["denoise_ratio"], noise=d("noise"))]
+        else:
+            raise KeyError(kind)
+    torch.cuda.synchronize()
+    return [o.detach().cpu().numpy() for o in out]
