@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HierSpeech++ vocoder path, batch 32 x 4 s per GPU (BASELINE.json
+configs[1]), 16 kHz output samples / s over the whole job + RTF.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+A step = one ``SynthesizerTrn.infer`` pass (style encoder -> SF prior encoder -> two
+reversed DiT coupling flows -> source network -> BigVGAN-style generator) over one batch
+of synthetic (mel, w2v, f0) already resident in HBM; weights are the synthetic recipe
+(no checkpoints exist offline).  Weak scaling: every rank synthesises its own 32
+utterances; rank 0 packs the weights and broadcasts the arena over RCCL.
+
+Printed JSON (one line, rank 0): metric/value per the driver contract plus
+  roofline     -- for the dominant kernel (conv1d_mfma_kernel): algorithmic FLOP of all
+                  its launches in one step / their summed duration, timed live with
+                  events on the launch stream, against the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline -- the CPU oracle (oracle/hsp_oracle.py) on this box's host cores on a
+                  bounded sample (B=1 x 4 s), N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=4.0, help="audio seconds per utterance")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from megatts2_hierspeechpp_amd import hip_layers, parallel, synth
+    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
+
+    rank, local_rank, world = parallel.init_distributed("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,
+               p_dropout=0.1, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+               upsample_rates=[4, 5, 4, 2, 2], upsample_initial_channel=1024, upsample_kernel_sizes=[8, 11, 8, 4, 4],
+               gin_channels=256)
+    net = SynthesizerTrn(641, 61440 // 320, **cfg)
+    sd_np = None
+    if rank == 0:  # only rank 0 materialises weights; the others receive the packed arena
+        sd_np = {k: synth.synth_tensor(k, tuple(v.shape), 0) for k, v in net.state_dict().items()}
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    arena = parallel.finalize_distributed(net, dev, src=0)
+
+    B, T = args.batch, int(round(args.seconds * 50))
+    inp = synth.synth_inputs(B, T, seed=20240 + rank)
+    d = lambda k: torch.from_numpy(inp[k]).to(dev)
+    mel, w2v, length, f0, noise = d("mel"), d("w2v"), d("length"), d("f0"), d("noise")
+
+    def step():
+        return net.infer(mel, w2v, length, f0, noise=noise)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = parallel.barrier_max(time.perf_counter() - t0, dev)
+    assert o.shape == (B, 1, 320 * T) and bool(torch.isfinite(o).all())
+
+    samples_per_step = world * B * 320 * T
+    audio_s_per_step = samples_per_step / 16000.0
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = samples_per_step * args.steps / elapsed
+
+    result = {
+        "metric": "16kHz audio samples/sec (whole node) + RTF, HierSpeech++ vocoder batch=32",
+        "value": value, "unit": "samples/s", "rtf": (elapsed / args.steps) / audio_s_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"vocoder-only infer(): {B} utterances x {args.seconds:g} s per GPU "
+                               f"(BASELINE.json configs[1]), synthetic weights", "batch_per_gpu": B,
+                   "frames": T, "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, "
+                   "one RCCL weight broadcast)", "weights_mb": arena.buffer.numel() * 4 / 1e6},
+    }
+
+    # ---- roofline of the dominant kernel, measured live (one extra instrumented step)
+    if not args.no_roofline:
+        rec = []
+        hip_layers.LAUNCH_HOOK = lambda kind, fl, nb, e0, e1: rec.append((kind, fl, nb, e0, e1))
+        step()
+        torch.cuda.synchronize()
+        hip_layers.LAUNCH_HOOK = None
+        mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1 in rec if kind == "hsp_conv1d_mfma_f32"]
+        tot_ms = sum(m for _, _, m in mf)
+        tot_fl = sum(f for f, _, _ in mf)
+        tot_b = sum(b for _, b, _ in mf)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "conv1d_mfma_kernel (all tile configs)", "bound": "mfma", "achieved": ach,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
+            "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,
+            "hbm_frac_of_8TBs": (tot_b / (tot_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+            "share_of_step_time": tot_ms / ms_per_step,
+        }
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import hsp_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+        ci = synth.synth_inputs(1, T, seed=20240)
+        t_ = lambda k: torch.from_numpy(ci[k])
+        run = lambda: O.synth_infer(sd, cfg, t_("mel"), t_("w2v"), t_("length"), t_("f0"), t_("noise"))
+        with torch.no_grad():
+            ro, _ = run()  # warm-up, also used for the on-box parity print
+            times = []
+            while len(times) < 3 and sum(times) < 25.0:
+                c0 = time.perf_counter()
+                run()
+                times.append(time.perf_counter() - c0)
+        best = sorted(times)[len(times) // 2]
+        # parity of the GPU path on the same utterance (rank-0 inputs, utterance 0)
+        with torch.no_grad():
+            g_ = lambda k: t_(k).to(dev)
+            go, _ = net.infer(g_("mel"), g_("w2v"), g_("length"), g_("f0"), noise=g_("noise"))
+        result["cpu_baseline"] = {
+            "value": 320 * T / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle synth_infer, 1 utterance x {args.seconds:g} s, median of {len(times)} runs "
+                      f"({best:.2f} s each)", "rtf": best / args.seconds,
+            "gpu_vs_oracle_maxabs": float((go.cpu() - ro).abs().max()),
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

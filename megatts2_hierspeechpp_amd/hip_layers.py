@@ -23,6 +23,23 @@ from . import _lib as L
 from .synth import kaiser_sinc_filter12
 
 
+# Optional measurement hook (bench.py): called as hook(kind, flops, bytes, ev_start, ev_end)
+# with torch.cuda.Events recorded around the launch on the launch stream.
+LAUNCH_HOOK = None
+
+
+def _launch(kind: str, fn, a, flops: int, nbytes: int):
+    hook = LAUNCH_HOOK
+    if hook is None:
+        L.check(fn(C.byref(a), L.stream_ptr()), kind)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(fn(C.byref(a), L.stream_ptr()), kind)
+    e1.record()
+    hook(kind, flops, nbytes, e0, e1)
+
+
 # ------------------------------------------------------------------ index maps (host logic)
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
@@ -215,10 +232,15 @@ class Conv1d(_ConvBase):
             a.prologue = L.PRO_SILU
         direct = (force_direct or self.stride != 1 or self.cin < 8 or cout < 8 or Lout < 8 or silu_in) \
             and not gated and act1d is None
+        rows_full = cout * (2 if gated else 1)
+        flops = 2 * B * rows_full * Cin * self.k * Lout
+        # algorithmic traffic: input once, output once (+ residual / accumulate reads), weights once
+        nbytes = 4 * (B * Cin * Lin + B * cout * Lout * (1 + (res is not None) + bool(accumulate))
+                      + rows_full * Cin * self.k)
         if direct:
-            L.check(L.lib().hsp_conv1d_direct_f32(C.byref(a), L.stream_ptr()), "hsp_conv1d_direct_f32")
+            _launch("hsp_conv1d_direct_f32", L.lib().hsp_conv1d_direct_f32, a, flops, nbytes)
         else:
-            L.check(L.lib().hsp_conv1d_mfma_f32(C.byref(a), L.stream_ptr()), "hsp_conv1d_mfma_f32")
+            _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
         return out
 
 
@@ -258,7 +280,9 @@ class ConvTranspose1d(_ConvBase):
         a.rows, a.up, a.shuf_pad = L.ROWS_SHUFFLE, self.up, self.padding
         a.bias = L.fptr(self._b)
         _set_epilogue(a, L.ACT_NONE, None, None, L.MASK_NONE, None, 1.0, res, False, 1.0, out)
-        L.check(L.lib().hsp_conv1d_mfma_f32(C.byref(a), L.stream_ptr()), "hsp_conv1d_mfma_f32")
+        flops = 2 * B * Cin * self.cout * self.k * Lin
+        nbytes = 4 * (B * Cin * Lin + B * self.cout * Lout * (1 + (res is not None)) + Cin * self.cout * self.k)
+        _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
         return out
 
 

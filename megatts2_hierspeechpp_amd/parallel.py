@@ -1,0 +1,70 @@
+"""Data-parallel batched synthesis: one process per GPU, utterances sharded in
+contiguous blocks, weights shipped once by an RCCL broadcast of the packed arena.
+
+The reference has no multi-GPU inference (four pinned copies of the script,
+inference_plm.py:336-339; SURVEY.md §2 'Parallelism').  Utterances are independent, so
+there is no data-path collective: the only communication is the start-up broadcast
+(SURVEY.md §8e)."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_distributed(backend: str = "nccl"):
+    """backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of utterances owned by ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20) -> torch.Tensor:
+    """Broadcast one flat buffer in large chunks (xGMI is point-to-point: few, large
+    transfers; 256 MiB chunks keep RCCL's ring pipelined without a huge staging need)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        flat = buf.view(-1)
+        for off in range(0, flat.numel(), chunk_elems):
+            dist.broadcast(flat[off:off + chunk_elems], src=src)
+    return buf
+
+
+def finalize_distributed(model, device, src: int = 0):
+    """Rank ``src`` folds + packs the weights; every other rank only lays the arena out
+    (identical offsets by construction) and receives the bytes by broadcast."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    arena = model.finalize(device, materialize=(rank == src))
+    broadcast_buffer(arena.buffer, src)
+    return arena
+
+
+def barrier_max(value: float, device) -> float:
+    """max over ranks of a python float (timing reduction of bench.py)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
