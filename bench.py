@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0, help="audio seconds per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--dump-launches", default=None, help="write a per-shape table of the conv launches here")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,8 +72,23 @@ def main():
     d = lambda k: torch.from_numpy(inp[k]).to(dev)
     mel, w2v, length, f0, noise = d("mel"), d("w2v"), d("length"), d("f0"), d("noise")
 
-    def step():
+    def eager_step():
         return net.infer(mel, w2v, length, f0, noise=noise)
+
+    # The whole forward (~830 launches) is captured once into a hipGraph and replayed:
+    # every launch of a step still executes, only the host-side submission cost goes.
+    eager_step()  # also sets kernel attributes (dynamic LDS sizes) outside the capture
+    torch.cuda.synchronize()
+    if args.no_graph:
+        step = eager_step
+    else:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = eager_step()
+
+        def step():
+            graph.replay()
+            return static_out
 
     for _ in range(args.warmup):
         step()
@@ -102,17 +119,30 @@ def main():
         "config": {"workload": f"vocoder-only infer(): {B} utterances x {args.seconds:g} s per GPU "
                                f"(BASELINE.json configs[1]), synthetic weights", "batch_per_gpu": B,
                    "frames": T, "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, "
-                   "one RCCL weight broadcast)", "weights_mb": arena.buffer.numel() * 4 / 1e6},
+                   "one RCCL weight broadcast)", "weights_mb": arena.buffer.numel() * 4 / 1e6,
+                   "launch_mode": "eager" if args.no_graph else "hipGraph replay of the captured step"},
     }
 
     # ---- roofline of the dominant kernel, measured live (one extra instrumented step)
     if not args.no_roofline:
         rec = []
-        hip_layers.LAUNCH_HOOK = lambda kind, fl, nb, e0, e1: rec.append((kind, fl, nb, e0, e1))
-        step()
+        hip_layers.LAUNCH_HOOK = lambda kind, fl, nb, e0, e1, la: rec.append(
+            (kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
+        eager_step()
         torch.cuda.synchronize()
         hip_layers.LAUNCH_HOOK = None
-        mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1 in rec if kind == "hsp_conv1d_mfma_f32"]
+        mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
+        if args.dump_launches and rank == 0:
+            agg = {}
+            for kind, fl, nb, e0, e1, shp in rec:
+                k = (kind,) + shp
+                n, f, m = agg.get(k, (0, 0, 0.0))
+                agg[k] = (n + 1, f + fl, m + e0.elapsed_time(e1))
+            with open(args.dump_launches, "w") as fh:
+                fh.write("kind Cin Cout K dil Lout prologue rows | launches gflop ms TF/s\n")
+                for k, (n, f, m) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                    fh.write(f"{k[0][4:-4]:14s} {k[1]:5d} {k[2]:5d} {k[3]:3d} {k[4]:2d} {k[5]:6d} {k[6]} {k[7]} | "
+                             f"{n:4d} {f / 1e9:10.1f} {m:9.3f} {f / (m * 1e-3) / 1e12:7.2f}\n")
         tot_ms = sum(m for _, _, m in mf)
         tot_fl = sum(f for f, _, _ in mf)
         tot_b = sum(b for _, b, _ in mf)
@@ -129,7 +159,9 @@ def main():
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import hsp_oracle as O
-        cores = os.cpu_count() or 1
+        # host threads: what the process may run on, capped -- torch's CPU convs stop scaling
+        # (and oversubscribe badly) far below the 256 logical CPUs of the GPU box
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
         torch.set_num_threads(cores)
         sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
         ci = synth.synth_inputs(1, T, seed=20240)

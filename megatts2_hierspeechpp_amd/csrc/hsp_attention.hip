@@ -9,6 +9,7 @@
 // LDS in 64-key slabs transposed so that lanes run along the head dimension.
 // Round-1 implementation on the vector pipe: T <= a few hundred on this path (50 Hz
 // frames), the whole attention work is ~10 % of the vocoder FLOPs.
+#include <atomic>
 #include "hsp_device.h"
 
 namespace {
@@ -149,10 +150,12 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   const int spad = a.Tk + 1;
   const int64_t lds_bytes = ((int64_t)a.D * QT + (int64_t)QT * spad + 64 * dpad) * (int64_t)sizeof(float);
   if (lds_bytes > 160 * 1024) return HSP_EINVAL;
-  if (lds_bytes > 32 * 1024) {
+  static std::atomic<int> lds_cap{32 * 1024};
+  if (lds_bytes > lds_cap.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
+    lds_cap.store(160 * 1024, std::memory_order_relaxed);
   }
   const int64_t blocks = (int64_t)n_qt * a.H * a.B;
   hipLaunchKernelGGL(mha_kernel, dim3((unsigned)blocks), dim3(ATT_THREADS), (size_t)lds_bytes,

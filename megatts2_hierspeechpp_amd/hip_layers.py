@@ -23,7 +23,7 @@ from . import _lib as L
 from .synth import kaiser_sinc_filter12
 
 
-# Optional measurement hook (bench.py): called as hook(kind, flops, bytes, ev_start, ev_end)
+# Optional measurement hook (bench.py): called as hook(kind, flops, bytes, ev_start, ev_end, args)
 # with torch.cuda.Events recorded around the launch on the launch stream.
 LAUNCH_HOOK = None
 
@@ -37,7 +37,7 @@ def _launch(kind: str, fn, a, flops: int, nbytes: int):
     e0.record()
     L.check(fn(C.byref(a), L.stream_ptr()), kind)
     e1.record()
-    hook(kind, flops, nbytes, e0, e1)
+    hook(kind, flops, nbytes, e0, e1, a)
 
 
 # ------------------------------------------------------------------ index maps (host logic)
