@@ -101,6 +101,7 @@ typedef struct hsp_conv1d_args {
   /* packed weights */
   const float* w;
   int32_t K, M, dil, pad, stride;
+  const float* zeros; /* >= 16 B of zeros, 16-B aligned (MFMA path: source of out-of-range DMA lanes) */
   int32_t w_ld; /* row count of the packed matrix w points into (>= M): lets a launch
                    use a row sub-range [r0, r0+M) by passing w + r0 (r0 % 4 == 0) */
   /* output */
@@ -130,6 +131,8 @@ typedef struct hsp_conv1d_args {
   int64_t res_bs, res_cs;
   int32_t accumulate;
   float post_scale;
+  int32_t debug; /* 0 in production.  Tuning aids (results are then WRONG): bit 0 = producers
+                    stage only the first chunk, bit 1 = consumers skip their MFMAs */
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) implicit-GEMM path; stride must be 1,

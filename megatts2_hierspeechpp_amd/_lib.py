@@ -30,7 +30,7 @@ class Conv1dArgs(C.Structure):
         ("x", _fp), ("x_bs", C.c_int64), ("x_cs", C.c_int64), ("x_ts", C.c_int64),
         ("B", C.c_int32), ("Cin", C.c_int32), ("Lin", C.c_int32),
         ("w", _fp), ("K", C.c_int32), ("M", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32), ("stride", C.c_int32),
-        ("w_ld", C.c_int32),
+        ("zeros", _fp), ("w_ld", C.c_int32),
         ("y", _fp), ("y_bs", C.c_int64), ("y_cs", C.c_int64),
         ("Cout", C.c_int32), ("Lout", C.c_int32), ("ncols", C.c_int32),
         ("prologue", C.c_int32), ("slope", C.c_float),
@@ -41,7 +41,7 @@ class Conv1dArgs(C.Structure):
         ("mask", _fp), ("mask_bs", C.c_int64), ("mask_mode", C.c_int32),
         ("cscale", _fp), ("cscale_bs", C.c_int64), ("scale", C.c_float),
         ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64),
-        ("accumulate", C.c_int32), ("post_scale", C.c_float),
+        ("accumulate", C.c_int32), ("post_scale", C.c_float), ("debug", C.c_int32),
     ]
 
 

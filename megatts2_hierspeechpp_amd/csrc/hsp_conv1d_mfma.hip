@@ -5,23 +5,25 @@
 //   acc[m, t] = sum_j sum_ci W[j][ci][m] * xin[ci, t + j*dil - pad]
 //
 // GEMM view: M = packed output rows, N = time, K = (taps x input channels).
-// One 512-thread workgroup owns a BM x BN output tile of one utterance and walks the
-// input channels in chunks of KC.  Its 8 waves are SPECIALISED:
+// One workgroup owns a BM x BN output tile of one utterance and walks the input
+// channels in chunks of KC.  Its waves are SPECIALISED:
 //
-//   waves 0-3  "consumers": each owns a (TM x TN) grid of 32x32 MFMA blocks and does
-//              nothing but read A (weights) / B (shifted input window) fragments from
-//              LDS and issue MFMAs;
-//   waves 4-7  "producers": stage the NEXT chunk into the other half of a double
-//              buffer -- the weight slab Ws[K][KC][BM] and the input window
-//              Xa[KC][BN + (K-1)*dil] -- applying the PROLOGUE on the way: nothing,
-//              leaky-ReLU, or the whole anti-aliased SnakeBeta activation (2x polyphase
-//              up-sample -> snake -> 2x low-pass down-sample, replicate-padded at the
-//              sequence ends exactly like alias_free_torch).  Each producer wave owns
-//              whole channel rows, so the three activation phases need only wave-local
-//              ordering, and the activated tensor never exists in HBM.
+//   waves 0-3   "consumers": each owns a (TM x TN) grid of 32x32 MFMA blocks and does
+//               nothing but read A (weights) / B (shifted input window) fragments from
+//               LDS -- one k-step ahead of the MFMAs that use them -- and issue MFMAs;
+//   waves 4..   "producers": stage the NEXT chunk into the other half of a double
+//               buffer -- the weight slab Ws[K][KC][BM] and the input window
+//               Xa[KC][BN + (K-1)*dil] -- applying the PROLOGUE on the way: nothing,
+//               leaky-ReLU, or the whole anti-aliased SnakeBeta activation (2x polyphase
+//               up-sample -> snake -> 2x low-pass down-sample, replicate-padded at the
+//               sequence ends exactly like alias_free_torch).  Each producer wave owns
+//               whole channel rows, so the activation phases need only wave-local
+//               ordering, and the activated tensor never exists in HBM.
+//               Global loads are issued one chunk AHEAD into registers (issue early /
+//               commit late), so their latency is covered by a whole chunk of MFMAs.
 //
-// Wave w and wave w+4 share a SIMD, so the producer's VALU/LDS/global work fills the
-// issue slots between the consumer's 64-cycle MFMAs; the only workgroup-wide
+// Wave w and wave w+4 share a SIMD, so the producers' VALU/LDS/global work fills the
+// issue slots between the consumers' 64-cycle MFMAs; the only workgroup-wide
 // synchronisation is one barrier per chunk.  The EPILOGUE (bias, conditioning bias,
 // gate / pointwise function, masks, per-channel scale, residual, running accumulation,
 // ConvTranspose phase shuffle) runs on the accumulator registers of the consumers.
@@ -35,39 +37,50 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int NCW = 4;               // consumer waves
-constexpr int NPW = 4;               // producer waves
-constexpr int THREADS = 64 * (NCW + NPW);
+constexpr int NCW = 4;    // consumer waves
 
-template <int WM, int WN, int TM, int TN, int KC>
+template <int WM, int WN, int TM, int TN, int NPW_, int MINW_>
 struct Cfg {
   static_assert(WM * WN == NCW, "four consumer waves");
-  static constexpr int kWM = WM, kWN = WN, kTM = TM, kTN = TN, kKC = KC;
+  static constexpr int kWM = WM, kWN = WN, kTM = TM, kTN = TN;
   static constexpr int BM = WM * TM * 32;
   static constexpr int BN = WN * TN * 32;
+  static constexpr int NPW = NPW_;                 // producer waves
+  static constexpr int NPT = NPW_ * 64;            // producer threads
+  static constexpr int THREADS = 64 * (NCW + NPW_);
+  static constexpr int MINW = MINW_;               // waves per SIMD the register allocation must allow
 };
 
 struct LdsPlan {
-  int xw;    // activated window width  = BN + (K-1)*dil
-  int xrw;   // raw window width        = xw + 10        (ACT1D)
-  int a2w;   // 2x-rate window width    = 2*xw + 10      (ACT1D)
+  int kc, lkc;  // chunk depth (power of two) and its log2
+  int rpw;      // channel rows per producer wave and chunk
+  int xw;       // activated window width  = BN + (K-1)*dil
+  int xwp;      // its LDS row pitch (multiple of 64: DMA instructions never straddle rows)
+  int xrw;      // raw window width        = xw + 10        (ACT1D)
+  int xrwp;     // raw row pitch in the producer scratch (multiple of 64)
+  int a2w;      // 2x-rate window width    = 2*xw + 10      (ACT1D)
   int ws_sz, xa_sz, scr_sz;  // floats: one weight slab, one window buffer, one producer scratch
-  int ws_off, xa_off, scr_off, total;
+  int xa_off, scr_off, total;
 };
 
 template <class C>
-__host__ __device__ inline LdsPlan make_plan(int K, int dil, int prologue) {
+__host__ __device__ inline LdsPlan make_plan(int K, int dil, int prologue, int lkc) {
   LdsPlan p;
+  p.lkc = lkc;
+  p.kc = 1 << lkc;
+  p.rpw = (p.kc + C::NPW - 1) / C::NPW;
   p.xw = C::BN + (K - 1) * dil;
+  p.xwp = (p.xw + 63) & ~63;
   p.xrw = p.xw + 10;
+  p.xrwp = (p.xrw + 63) & ~63;
   p.a2w = 2 * p.xw + 10;
-  p.ws_sz = K * C::kKC * C::BM;
-  p.xa_sz = (C::kKC * p.xw + 3) & ~3;
-  p.scr_sz = prologue == HSP_PRO_ACT1D ? ((p.xrw + p.a2w + 3) & ~3) : 0;
-  p.ws_off = 0;
+  p.ws_sz = K * p.kc * C::BM;
+  p.xa_sz = p.kc * p.xwp;
+  // scratch of one producer wave: double-buffered raw rows + one 2x-rate row
+  p.scr_sz = prologue == HSP_PRO_ACT1D ? 2 * p.rpw * p.xrwp + ((p.a2w + 3) & ~3) : 0;
   p.xa_off = 2 * p.ws_sz;
   p.scr_off = p.xa_off + 2 * p.xa_sz;
-  p.total = p.scr_off + NPW * p.scr_sz;
+  p.total = p.scr_off + C::NPW * p.scr_sz;
   return p;
 }
 
@@ -79,94 +92,188 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// workgroup barrier that does NOT drain outstanding global loads: only this wave's LDS
+// traffic has to be complete before the other role touches the buffer (__syncthreads()
+// would add s_waitcnt vmcnt(0) and expose the latency of the prefetched chunk)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // wave-local LDS ordering: all earlier LDS ops of this wave are complete and the
 // compiler may not move memory accesses across this point
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// ------------------------------------------------------------------- producer side
+// Only the fields the producers touch, held by value (a reference to the by-value kernel
+// argument inside an aggregate makes the compiler spill the whole struct to scratch).
+struct ProdArgs {
+  const float* w;
+  const float* zeros;      // >= 16 B of zeros: source of every out-of-range DMA lane
+  const float* alpha_exp;
+  const float* beta_inv;
+  const float* filt;
+  int K, Cin, Lin, M, w_ld, x_cs, x_ts, prologue;
+  float slope;
+};
+
+// LDS-DMA (global_load_lds): each lane supplies a global address, the data lands at
+// lds_base + lane * BYTES with no register staging; counted in vmcnt like a load.
+#define HSP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define HSP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds(HSP_GPTR(g), HSP_LPTR(l), 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds(HSP_GPTR(g), HSP_LPTR(l), 4, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <class C>
-__device__ __forceinline__ void produce_chunk(const hsp_conv1d_args& a, const LdsPlan& P, float* __restrict__ Ws,
-                                              float* __restrict__ Xa, float* __restrict__ scr, const float* xb,
-                                              int c0, int m0, int p0, int pw, int lane) {
-  constexpr int BM = C::BM, KC = C::kKC;
-  const int L = a.Lin;
-  // ---- weight slab: Ws[j][kc][mm] = w[j][c0+kc][m0+mm]
-  {
-    const int nvec = a.K * KC * (BM / 4);
-    for (int v = pw * 64 + lane; v < nvec; v += NPW * 64) {
-      const int mm4 = v % (BM / 4);
-      const int rest = v / (BM / 4);
-      const int kc = rest % KC, j = rest / KC;
-      const int ci = c0 + kc, m = m0 + mm4 * 4;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ci < a.Cin && m < a.M) val = *reinterpret_cast<const float4*>(a.w + ((int64_t)j * a.Cin + ci) * a.w_ld + m);
-      *reinterpret_cast<float4*>(Ws + (j * KC + kc) * BM + mm4 * 4) = val;
+struct Prod {
+  static constexpr int CPR = C::BM / 4;                       // float4 columns per slab row
+  static constexpr int RPI = (64 / CPR) > 0 ? (64 / CPR) : 1;  // slab rows per DMA instruction
+
+  // ---- weight slab of chunk c0 -> Ws[j][kc][BM]: rows (j, c0+kc) of the packed matrix
+  static __device__ __forceinline__ void dma_w(const ProdArgs& a, const LdsPlan& P, float* Ws, int c0, int m0, int pw,
+                                               int lane) {
+    const int r_in = lane / CPR, col = (lane % CPR) * 4;
+    const int lipj = P.lkc - __builtin_ctz(RPI);  // log2(instructions per tap); KC >= RPI
+    const int ninstr = a.K << lipj;
+    const bool colok = m0 + col < a.M;
+    const float* wcol = a.w + m0 + col;
+    for (int q = pw; q < ninstr; q += C::NPW) {
+      const int j = q >> lipj, g = q & ((1 << lipj) - 1);
+      const int ci = c0 + g * RPI + r_in;
+      const float* src = (colok && ci < a.Cin) ? wcol + (j * a.Cin + ci) * a.w_ld : a.zeros;
+      dma16(src, Ws + ((j << P.lkc) + g * RPI) * C::BM);
     }
   }
-  // ---- input window rows owned by this producer wave
-  if (a.prologue != HSP_PRO_ACT1D) {
-    for (int kc = pw; kc < KC; kc += NPW) {
+
+  // ---- plain window rows -> Xa[kc][xwp] (zero outside [0, Lin) and beyond Cin)
+  static __device__ __forceinline__ void dma_x(const ProdArgs& a, const LdsPlan& P, float* Xa, const float* xb, int c0,
+                                               int p0, int pw, int lane) {
+    const int npr = P.xwp >> 6;
+    for (int kc = pw; kc < P.kc; kc += C::NPW) {
       const int ci = c0 + kc;
-      const float* xc = xb + (int64_t)ci * a.x_cs;
-      for (int s = lane; s < P.xw; s += 64) {
-        const int p = p0 + s;
-        float v = 0.0f;
-        if (ci < a.Cin && p >= 0 && p < L) {
-          v = xc[(int64_t)p * a.x_ts];
-          if (a.prologue == HSP_PRO_LRELU) v = v > 0.0f ? v : v * a.slope;
-        }
-        Xa[kc * P.xw + s] = v;
+      const float* xc = xb + ci * a.x_cs;
+      for (int i = 0; i < npr; ++i) {
+        const int p = p0 + lane + 64 * i;
+        const float* src = (ci < a.Cin && p >= 0 && p < a.Lin) ? xc + p * a.x_ts : a.zeros;
+        dma4(src, Xa + kc * P.xwp + 64 * i);
       }
     }
-    return;
   }
-  float* const raw = scr;          // [xrw]  x[clamp(p0-5+s)]
-  float* const a2 = scr + P.xrw;   // [a2w]  snake(up2x)[clamp(2*p0-5+s)]
-  const int mlo = 2 * p0 - 5;
-  for (int kc = pw; kc < KC; kc += NPW) {
-    const int ci = c0 + kc;
-    float* const xa = Xa + kc * P.xw;
-    if (ci >= a.Cin) {
-      for (int s = lane; s < P.xw; s += 64) xa[s] = 0.0f;
-      continue;
+  static __device__ __forceinline__ void lrelu_x(const ProdArgs& a, const LdsPlan& P, float* Xa, int pw, int lane) {
+    for (int kc = pw; kc < P.kc; kc += C::NPW)
+      for (int s = lane; s < P.xwp; s += 64) {
+        const float v = Xa[kc * P.xwp + s];
+        Xa[kc * P.xwp + s] = v > 0.0f ? v : v * a.slope;
+      }
+  }
+
+  // ---- ACT1D: raw rows (replicate padding = index clamp) -> this wave's scratch
+  static __device__ __forceinline__ void dma_raw(const ProdArgs& a, const LdsPlan& P, float* rawbuf, const float* xb,
+                                                 int c0, int p0, int pw, int lane) {
+    const int npr = P.xrwp >> 6;
+    for (int rs = 0; rs < P.rpw; ++rs) {
+      const int ci = c0 + pw + rs * C::NPW;
+      const float* xc = xb + ci * a.x_cs;
+      for (int i = 0; i < npr; ++i) {
+        const float* src = ci < a.Cin ? xc + hsp_clampi(p0 - 5 + lane + 64 * i, 0, a.Lin - 1) : a.zeros;
+        dma4(src, rawbuf + rs * P.xrwp + 64 * i);
+      }
     }
-    const float* xc = xb + (int64_t)ci * a.x_cs;
-    const float ea = a.alpha_exp[ci], binv = a.beta_inv[ci];
-    // phase A: raw samples, replicate-padded (index clamp) -- F.pad(mode='replicate')
-    for (int s = lane; s < P.xrw; s += 64) raw[s] = xc[hsp_clampi(p0 - 5 + s, 0, L - 1)];
-    wave_lds_fence();
-    // phase B: a[m] = snake(2 * up[m]); even m=2q: taps h[11],h[9],..,h[1] on x[q-3..q+2],
-    //          odd m=2q+1: taps h[10],h[8],..,h[0] on x[q-2..q+3]
-    for (int s = lane; s < P.a2w; s += 64) {
-      const int m = hsp_clampi(mlo + s, 0, 2 * L - 1);
-      const int q = m >> 1, odd = m & 1;
-      const float* xr = raw + (q - 3 + odd) - (p0 - 5);
-      float u = 0.0f;
+  }
+
+  // one channel row: raw (LDS) -> 2x-rate snake signal (LDS) -> activated window row.
+  // VALU cycles here are stolen from the fp32 MFMAs of the consumer wave on the same SIMD
+  // (they share the fp32 datapath), so the arithmetic is kept minimal: packed fp32 FMAs
+  // (v_pk_fma_f32: an even and an odd output sample per lane) and hardware cosine.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void act_row(const ProdArgs& a, const LdsPlan& P, const float* raw, float* a2,
+                                                 float* xa, int ci, int p0, int lane) {
+    const int L = a.Lin;
+    const int mlo = 2 * p0 - 5;
+    const bool interior = mlo >= 0 && mlo + P.a2w <= 2 * L;  // no index clamp needed at the 2x rate
+    const float* hu = a.filt;
+    const float* hd = a.filt + 12;
+    const int cic = ci < a.Cin ? ci : a.Cin - 1;
+    const float kf = a.alpha_exp[cic] * 0.318309886183790672f, kb = 0.5f * a.beta_inv[cic];
+    // phase B: a[m] = snake(2 * up[m]);  up[2q]   = sum_i x[q-3+i] * hu[11-2i],
+    //                                    up[2q+1] = sum_i x[q-2+i] * hu[10-2i]   (i = 0..5)
+    if (interior) {
+      // slot 2i+1 <-> m = 2q (q = p0-2+i), slot 2i+2 <-> m = 2q+1: both read raw[i .. i+6]
+      const int npair = (P.a2w - 1) >> 1;
+      for (int i = lane; i < npair; i += 64) {
+        float xv[7];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) u = fmaf(xr[i], odd ? a.filt[10 - 2 * i] : a.filt[11 - 2 * i], u);
-      a2[s] = hsp_snake(2.0f * u, ea, binv);
+        for (int t = 0; t < 7; ++t) xv[t] = raw[i + t];
+        f32x2 u = {0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const f32x2 xx = {xv[t], xv[t + 1]};
+          const f32x2 hh = {hu[11 - 2 * t], hu[10 - 2 * t]};
+          u = __builtin_elementwise_fma(xx, hh, u);
+        }
+        u = u * 2.0f;
+        a2[2 * i + 1] = hsp_snake_hw(u.x, kf, kb);
+        a2[2 * i + 2] = hsp_snake_hw(u.y, kf, kb);
+      }
+      if (lane < 2) {  // slot 0 (odd m, q = p0-3, raw[0..5]) and the last slot (even m, raw[xw+4..xw+9])
+        const float* xr_ = lane ? raw + P.xw + 4 : raw;
+        float uu = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) uu = fmaf(xr_[t], lane ? hu[11 - 2 * t] : hu[10 - 2 * t], uu);
+        a2[lane ? P.a2w - 1 : 0] = hsp_snake_hw(2.0f * uu, kf, kb);
+      }
+    } else {
+      for (int s = lane; s < P.a2w; s += 64) {
+        const int m = hsp_clampi(mlo + s, 0, 2 * L - 1);
+        const int q = m >> 1, odd = m & 1;
+        const float* xr_ = raw + (q - 3 + odd) - (p0 - 5);
+        float u = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) u = fmaf(xr_[t], odd ? hu[10 - 2 * t] : hu[11 - 2 * t], u);
+        a2[s] = hsp_snake_hw(2.0f * u, kf, kb);
+      }
     }
     wave_lds_fence();
     // phase C: y[p] = sum_k hd[k] * a[clamp(2p+k-5)], zero outside [0, L) (conv zero padding)
-    for (int s = lane; s < P.xw; s += 64) {
+    for (int s = lane; s < P.xwp; s += 64) {
       const int p = p0 + s;
-      float v = 0.0f;
-      if (p >= 0 && p < L) {
-        const float* ar = a2 + 2 * s;
+      f32x2 v = {0.0f, 0.0f};
+      if (p >= 0 && p < L && s < P.xw) {
+        const f32x2* ar = reinterpret_cast<const f32x2*>(a2 + 2 * s);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) v = fmaf(a.filt[12 + k], ar[k], v);
+        for (int k = 0; k < 6; ++k) {
+          const f32x2 hh = {hd[2 * k], hd[2 * k + 1]};
+          v = __builtin_elementwise_fma(ar[k], hh, v);
+        }
       }
-      xa[s] = v;
+      xa[s] = v.x + v.y;
     }
-    wave_lds_fence();  // raw / a2 are reused by the next row
+    wave_lds_fence();  // a2 is reused by the next row
   }
-}
 
+  static __device__ __forceinline__ void act_rows(const ProdArgs& a, const LdsPlan& P, const float* rawbuf, float* a2,
+                                                  float* Xa, int c0, int p0, int pw, int lane) {
+    for (int rs = 0; rs < P.rpw; ++rs) {
+      const int row = pw + rs * C::NPW;
+      if (row < P.kc) act_row(a, P, rawbuf + rs * P.xrwp, a2, Xa + row * P.xwp, c0 + row, p0, lane);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------ kernel
 template <class C>
-__global__ __launch_bounds__(THREADS) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
-                                                              const int n_nt) {
+__global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
+                                                                 const int n_nt, const int lkc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int BM = C::BM, BN = C::BN, KC = C::kKC, TM = C::kTM, TN = C::kTN;
-  const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue);
+  constexpr int BM = C::BM, BN = C::BN, TM = C::kTM, TN = C::kTN;
+  const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
+  const int KC = P.kc;
 
   // blockIdx.x = mt + n_mt * (nt + n_nt * b): row tiles fastest, so the blocks that
   // round-robin onto one XCD keep hitting the same weight slab in that XCD's L2.
@@ -180,21 +287,54 @@ __global__ __launch_bounds__(THREADS) void conv1d_mfma_kernel(const hsp_conv1d_a
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int nchunks = (a.Cin + KC - 1) / KC;
+  const int nchunks = (a.Cin + KC - 1) >> lkc;
 
   if (wave >= NCW) {
     // ------------------------------------------------------------ producers
     const int pw = wave - NCW;
+    const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
+                      (int)a.x_ts, a.prologue, a.slope};
     const float* xb = a.x + (int64_t)b * a.x_bs;
-    float* scr = lds + P.scr_off + pw * P.scr_sz;
-    produce_chunk<C>(a, P, lds + P.ws_off, lds + P.xa_off, scr, xb, 0, m0, p0, pw, lane);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      const int nb = (c + 1) & 1;
-      if (c + 1 < nchunks)
-        produce_chunk<C>(a, P, lds + P.ws_off + nb * P.ws_sz, lds + P.xa_off + nb * P.xa_sz, scr, xb, (c + 1) * KC, m0,
-                         p0, pw, lane);
-      __syncthreads();
+    using PR = Prod<C>;
+    float* const Ws0 = lds;
+    float* const Xa0 = lds + P.xa_off;
+    if (a.prologue != HSP_PRO_ACT1D) {
+      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
+      PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
+      wait_vm0();
+      if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
+      lds_barrier();
+      for (int c = 0; c < nchunks; ++c) {
+        const int nb = (c + 1) & 1;
+        if (c + 1 < nchunks && !(a.debug & 1)) {
+          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
+          PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
+          wait_vm0();
+          if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
+        }
+        lds_barrier();
+      }
+    } else {
+      float* const scr = lds + P.scr_off + pw * P.scr_sz;   // raw[2][rpw][xrwp], a2[a2w]
+      float* const a2 = scr + 2 * P.rpw * P.xrwp;
+      const int rsz = P.rpw * P.xrwp;
+      PR::dma_raw(pa, P, scr, xb, 0, p0, pw, lane);
+      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
+      wait_vm0();
+      PR::act_rows(pa, P, scr, a2, Xa0, 0, p0, pw, lane);
+      if (nchunks > 1) PR::dma_raw(pa, P, scr + rsz, xb, KC, p0, pw, lane);
+      wait_vm0();
+      lds_barrier();
+      for (int c = 0; c < nchunks; ++c) {
+        const int nb = (c + 1) & 1;
+        if (c + 1 < nchunks && !(a.debug & 1)) {
+          if (!(a.debug & 8)) PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
+          if (c + 2 < nchunks) PR::dma_raw(pa, P, scr + (c & 1) * rsz, xb, (c + 2) << lkc, p0, pw, lane);
+          if (!(a.debug & 4)) PR::act_rows(pa, P, scr + nb * rsz, a2, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0, pw, lane);
+          wait_vm0();
+        }
+        lds_barrier();
+      }
     }
     return;
   }
@@ -210,29 +350,54 @@ __global__ __launch_bounds__(THREADS) void conv1d_mfma_kernel(const hsp_conv1d_a
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  __syncthreads();  // chunk 0 staged
+  const int wlane = half * BM + wm * (TM * 32) + l32;
+  const int xlane = half * P.xwp + wn * (TN * 32) + l32;
+  const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4
+  const int a_step = KC * BM;          // next tap, same channel pair
+
+  lds_barrier();  // chunk 0 staged
   for (int c = 0; c < nchunks; ++c) {
     const int cb = c & 1;
-    const float* wbase = lds + P.ws_off + cb * P.ws_sz + half * BM + wm * (TM * 32) + l32;
-    const float* xbase = lds + P.xa_off + cb * P.xa_sz + half * P.xw + wn * (TN * 32) + l32;
-    for (int j = 0; j < a.K; ++j) {
-      const float* wj = wbase + j * (KC * BM);
-      const float* xj = xbase + j * a.dil;
+    const float* const ws = lds + cb * P.ws_sz + wlane;
+    const float* const xs = lds + P.xa_off + cb * P.xa_sz + xlane;
+    // k-steps ordered channel-pair outer, tap inner: A += KC*BM, B += dil per step
+    const float* pa = ws;
+    const float* pb = xs;
+    int j = 0, kk = 0;
+    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        float fa[TM], fb[TN];
+    for (int i = 0; i < TM; ++i) fa0[i] = pa[i * 32];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = wj[(2 * kk) * BM + i * 32];
+    for (int i = 0; i < TN; ++i) fb0[i] = pb[i * 32];
+    for (int s = (a.debug & 2) ? nsteps : 0; s < nsteps; s += 2) {
+      // ---- prefetch step s+1 into set 1, multiply set 0
+      pa += a_step; pb += a.dil;
+      if (++j == a.K) { j = 0; ++kk; pa = ws + 2 * kk * BM; pb = xs + 2 * kk * P.xwp; }
 #pragma unroll
-        for (int i = 0; i < TN; ++i) fb[i] = xj[(2 * kk) * P.xw + i * 32];
+      for (int i = 0; i < TM; ++i) fa1[i] = pa[i * 32];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TN; ++i) fb1[i] = pb[i * 32];
 #pragma unroll
-          for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i], fb0[n], acc[i][n], 0, 0, 0);
+      // ---- prefetch step s+2 into set 0 (skipped on the last trip)
+      pa += a_step; pb += a.dil;
+      if (++j == a.K) { j = 0; ++kk; pa = ws + 2 * kk * BM; pb = xs + 2 * kk * P.xwp; }
+      if (s + 2 < nsteps) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa0[i] = pa[i * 32];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb0[i] = pb[i * 32];
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i], fb1[n], acc[i][n], 0, 0, 0);
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- epilogue.  C/D map of the 32x32 forms: col = lane & 31,
@@ -301,28 +466,46 @@ __global__ __launch_bounds__(THREADS) void conv1d_mfma_kernel(const hsp_conv1d_a
   }
 }
 
+// -------------------------------------------------------------------- host side
 constexpr int kMaxLdsBytes = 160 * 1024;
+constexpr int kLdsTarget = 80 * 1024;  // two workgroups per CU when possible
 
+// largest chunk depth (log2) this tile shape can stage for the launch, or -1
 template <class C>
-int lds_bytes_of(const hsp_conv1d_args& a) {
-  return make_plan<C>(a.K, a.dil, a.prologue).total * (int)sizeof(float);
+int pick_lkc(const hsp_conv1d_args& a, int lds_limit) {
+  const bool act = a.prologue == HSP_PRO_ACT1D;
+  int cin_p2 = 2;
+  while ((1 << cin_p2) < a.Cin && cin_p2 < 6) ++cin_p2;  // no point staging past Cin
+  for (int lkc = cin_p2; lkc >= 2; --lkc) {
+    const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
+    if (P.total * (int)sizeof(float) > lds_limit) continue;
+    if (P.kc < Prod<C>::RPI) continue;   // a weight DMA instruction must stay inside one tap
+    if (act && P.rpw > 2) continue;      // activation work per producer wave and chunk
+    return lkc;
+  }
+  return -1;
 }
 
 template <class C>
 int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
-  const int lds_bytes = lds_bytes_of<C>(a);
+  int lkc = pick_lkc<C>(a, kLdsTarget);
+  if (lkc < 3) {
+    const int l2 = pick_lkc<C>(a, kMaxLdsBytes);
+    if (l2 > lkc) lkc = l2;
+  }
+  if (lkc < 0) return HSP_EINVAL;
+  const int lds_bytes = make_plan<C>(a.K, a.dil, a.prologue, lkc).total * (int)sizeof(float);
   if (plan_out) {
-    plan_out[0] = C::BM; plan_out[1] = C::BN; plan_out[2] = C::kKC; plan_out[3] = lds_bytes;
+    plan_out[0] = C::BM; plan_out[1] = C::BN; plan_out[2] = 1 << lkc; plan_out[3] = lds_bytes;
     return 0;
   }
-  if (lds_bytes > kMaxLdsBytes) return HSP_EINVAL;
   const int n_mt = (a.M + C::BM - 1) / C::BM;
   const int n_nt = (a.ncols + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
   if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
   auto kern = conv1d_mfma_kernel<C>;
-  // raise the kernel's dynamic-LDS cap once per size (idempotent; kept out of the launch
-  // path afterwards so that launches are legal inside a hipGraph stream capture)
+  // raise the kernel's dynamic-LDS cap once (idempotent; kept out of the launch path
+  // afterwards so that launches are legal inside a hipGraph stream capture)
   static std::atomic<int> lds_cap{32 * 1024};
   if (lds_bytes > lds_cap.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -330,7 +513,7 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     if (e != hipSuccess) return (int)e;
     lds_cap.store(kMaxLdsBytes, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, s, a, n_mt, n_nt);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc);
   return (int)hipGetLastError();
 }
 
@@ -340,7 +523,11 @@ int validate(const hsp_conv1d_args& a) {
     return HSP_EINVAL;
   if (a.stride != 1 || (a.M & 3) || (a.w_ld & 3) || a.w_ld < a.M || a.dil < 1) return HSP_EINVAL;
   if ((reinterpret_cast<uintptr_t>(a.w) & 15) != 0) return HSP_EINVAL;
+  // the kernel indexes one utterance / the weight matrix with 32-bit element offsets
+  if ((int64_t)a.K * a.Cin * a.w_ld >= (1ll << 31)) return HSP_EINVAL;
+  if ((int64_t)a.Cin * a.x_cs + (int64_t)a.Lin * a.x_ts >= (1ll << 31) || a.x_cs < 0 || a.x_ts < 0) return HSP_EINVAL;
   if (a.prologue == HSP_PRO_ACT1D && (!a.alpha_exp || !a.beta_inv || !a.filt || a.x_ts != 1)) return HSP_EINVAL;
+  if (!a.zeros || (reinterpret_cast<uintptr_t>(a.zeros) & 15) != 0) return HSP_EINVAL;
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_ACT1D) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
   if (a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU) {
@@ -353,32 +540,34 @@ int validate(const hsp_conv1d_args& a) {
   return 0;
 }
 
-// tile configurations <WM, WN, TM, TN, KC>; the chunk depth KC is picked per launch so
-// that the double-buffered weight slab (2 * K * KC * BM floats) fits LDS
-template <int KC> using M256 = Cfg<2, 2, 4, 2, KC>;  // 256 x 128
-template <int KC> using M128 = Cfg<2, 2, 2, 2, KC>;  // 128 x 128
-template <int KC> using M64 = Cfg<1, 4, 2, 2, KC>;   //  64 x 256
-template <int KC> using M32 = Cfg<1, 4, 1, 4, KC>;   //  32 x 512
-template <int KC> using M64S = Cfg<1, 4, 2, 1, KC>;  //  64 x 128  (short sequences)
-template <int KC> using M32S = Cfg<1, 4, 1, 1, KC>;  //  32 x 128  (short sequences)
-
-constexpr int kLdsTarget = 80 * 1024;  // two workgroups per CU when possible
-
-template <template <int> class T>
-int launch_kc(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
-  if (lds_bytes_of<T<16>>(a) <= kLdsTarget) return launch<T<16>>(a, s, plan_out);
-  if (lds_bytes_of<T<8>>(a) <= kLdsTarget) return launch<T<8>>(a, s, plan_out);
-  if (lds_bytes_of<T<4>>(a) <= kLdsTarget) return launch<T<4>>(a, s, plan_out);
-  if (lds_bytes_of<T<8>>(a) <= kMaxLdsBytes) return launch<T<8>>(a, s, plan_out);
-  return launch<T<4>>(a, s, plan_out);
-}
+// tile shapes <WM, WN, TM, TN, producer waves, min waves per SIMD>
+using M256 = Cfg<2, 2, 4, 2, 4, 2>;    // 256 x 128, one workgroup per CU
+using M128 = Cfg<2, 2, 2, 2, 4, 2>;    // 128 x 128
+using M64 = Cfg<1, 4, 2, 2, 8, 3>;     //  64 x 256
+using M32 = Cfg<1, 4, 1, 4, 8, 3>;     //  32 x 512
+using S64 = Cfg<2, 2, 1, 1, 4, 2>;     //  64 x 64   short sequences: many small, deep-chunk tiles
+using S64G = Cfg<1, 4, 2, 1, 4, 2>;    //  64 x 128  short sequences, gated rows (needs TM even)
+using S32 = Cfg<1, 4, 1, 1, 4, 2>;     //  32 x 128
 
 int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
-  const bool short_seq = a.ncols <= 1024;
-  if (a.M > 128) return launch_kc<M256>(a, s, plan_out);
-  if (a.M > 64) return launch_kc<M128>(a, s, plan_out);
-  if (a.M > 32) return short_seq ? launch_kc<M64S>(a, s, plan_out) : launch_kc<M64>(a, s, plan_out);
-  return short_seq ? launch_kc<M32S>(a, s, plan_out) : launch_kc<M32>(a, s, plan_out);
+#ifdef HSP_ONLY_CFG
+  return launch<HSP_ONLY_CFG>(a, s, plan_out);
+#else
+  const bool gated = a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU;
+  // "short": the whole launch offers few tiles; prefer small tiles with deep chunks so that
+  // every CU gets work and each tile sees few global-load round trips
+  const int64_t cols = (int64_t)a.B * a.ncols;
+  const bool short_seq = a.ncols <= 256 && (int64_t)((a.M + 255) / 256) * ((cols + 127) / 128) < 512;
+  if (short_seq) {
+    if (gated) return launch<S64G>(a, s, plan_out);
+    if (a.M > 32) return launch<S64>(a, s, plan_out);
+    return launch<S32>(a, s, plan_out);
+  }
+  if (a.M > 128) return launch<M256>(a, s, plan_out);
+  if (a.M > 64) return launch<M128>(a, s, plan_out);
+  if (a.M > 32) return launch<M64>(a, s, plan_out);
+  return launch<M32>(a, s, plan_out);
+#endif
 }
 
 }  // namespace

@@ -51,6 +51,16 @@ __device__ __forceinline__ float hsp_snake(float x, float ea, float binv) {
   return fmaf(binv, s * s, x);
 }
 
+// Hardware-trig form used inside the fused conv prologue, where every VALU cycle is taken
+// from the fp32 MFMAs running on the same SIMD:  sin^2(y) = (1 - cos 2y) / 2 with
+// v_cos_f32 (argument in revolutions, reduced by v_fract_f32):
+//   snake(x) = (x + kb) - kb * cos(2*pi * fract(x * kf)),   kf = exp(alpha)/pi, kb = binv/2
+// 5 VALU ops instead of 14.  v_cos_f32 is accurate to ~1e-6 absolute on [0, 1).
+__device__ __forceinline__ float hsp_snake_hw(float x, float kf, float kb) {
+  const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * kf));
+  return fmaf(-kb, c, x + kb);
+}
+
 __device__ __forceinline__ int hsp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Shared epilogue of both conv kernels for one output element in PLAIN/SHUFFLE row

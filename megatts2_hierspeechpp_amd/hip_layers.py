@@ -26,9 +26,22 @@ from .synth import kaiser_sinc_filter12
 # Optional measurement hook (bench.py): called as hook(kind, flops, bytes, ev_start, ev_end, args)
 # with torch.cuda.Events recorded around the launch on the launch stream.
 LAUNCH_HOOK = None
+DEBUG_FLAGS = 0  # hsp_conv1d_args.debug for every conv launch (kernel tuning only)
+
+
+_ZEROS = {}
+
+
+def _zeros(device) -> torch.Tensor:
+    """64 zero floats per device: the source of out-of-range LDS-DMA lanes (hsp_conv1d_args.zeros)."""
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(64, dtype=torch.float32, device=device)
+    return z
 
 
 def _launch(kind: str, fn, a, flops: int, nbytes: int):
+    a.debug = DEBUG_FLAGS
     hook = LAUNCH_HOOK
     if hook is None:
         L.check(fn(C.byref(a), L.stream_ptr()), kind)
@@ -218,6 +231,7 @@ class Conv1d(_ConvBase):
         a.w, a.K, a.dil, a.pad, a.stride = L.fptr(self._w) + 4 * r0, self.k, self.dilation, self.padding, self.stride
         a.M = self.M if row_range is None else _round_up(cout, 4)
         a.w_ld = self.M
+        a.zeros = L.fptr(_zeros(x.device))
         _set_out(a, out, B, cout, Lout)
         a.ncols = Lout
         a.rows, a.gate_half = self.rows, (cout if gated else 0)
@@ -275,6 +289,7 @@ class ConvTranspose1d(_ConvBase):
         a.B, a.Cin, a.Lin = B, Cin, Lin
         a.w, a.K, a.M, a.dil, a.pad, a.stride = L.fptr(self._w), self.kp, self.M, 1, self.kp - 1, 1
         a.w_ld = self.M
+        a.zeros = L.fptr(_zeros(x.device))
         _set_out(a, out, B, self.cout, Lout)
         a.ncols = (Lout - 1 + self.padding) // self.up + 1
         a.rows, a.up, a.shuf_pad = L.ROWS_SHUFFLE, self.up, self.padding
