@@ -269,7 +269,8 @@ struct Prod {
 // ------------------------------------------------------------------------ kernel
 template <class C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
-                                                                 const int n_nt, const int lkc) {
+                                                                 const int n_nt, const int lkc,
+                                                                 const int epi_vec) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = C::BM, BN = C::BN, TM = C::kTM, TN = C::kTN;
   const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
@@ -404,19 +405,107 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
   //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   // static_for keeps every accumulator index a compile-time constant: a runtime index
   // into acc[][] would demote the whole accumulator file to scratch memory.
+  if (a.debug & 16) return;
   const int mw = m0 + wm * (TM * 32);
   const int tw = t0 + wn * (TN * 32) + l32;
+  if (epi_vec) {
+    // Vector epilogue (plain rows, 16-B aligned tensors): each 32x32 accumulator block is
+    // transposed through this wave's LDS staging area (the weight buffers are free after the
+    // last barrier) so that a lane owns 4 consecutive time steps of 4 rows -> float4 residual /
+    // accumulate loads and float4 stores.  The common case (no pointwise function, mask or
+    // per-channel scale: every AMP / ConvTranspose-free conv of the generator) gets a branch-
+    // and spill-free body; a scratch reload or a late constant load inside this loop would
+    // wait on vmcnt, which also drains every older store.
+    constexpr int ESTR = 36;
+    float* const stage = lds + wave * (32 * ESTR);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto run = [&](auto fast_tag) __attribute__((always_inline)) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      static_for<TM>([&](auto ii) __attribute__((always_inline)) {
+        constexpr int i = decltype(ii)::value;
+        float add[4], cs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = mw + i * 32 + er + 8 * q;
+          add[q] = 0.0f;
+          cs[q] = a.scale;
+          if (co < a.Cout) {
+            if (a.bias) add[q] = a.bias[co];
+            if constexpr (!FAST) {
+              if (a.cbias) add[q] += a.cbias[(int64_t)b * a.cbias_bs + co];
+              if (a.cscale) cs[q] *= a.cscale[(int64_t)b * a.cscale_bs + co];
+            }
+          }
+        }
+        static_for<TN>([&](auto nn) __attribute__((always_inline)) {
+          constexpr int n = decltype(nn)::value;
+          const int t = t0 + wn * (TN * 32) + n * 32 + ec;
+          const bool tok = t < a.ncols;
+          float4 rs[4], yo[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int co = mw + i * 32 + er + 8 * q;
+            const bool ok = tok && co < a.Cout;
+            rs[q] = z4;
+            yo[q] = z4;
+            if (ok && a.res) rs[q] = *reinterpret_cast<const float4*>(a.res + (int64_t)b * a.res_bs + (int64_t)co * a.res_cs + t);
+            if (ok && a.accumulate) yo[q] = *reinterpret_cast<const float4*>(a.y + (int64_t)b * a.y_bs + (int64_t)co * a.y_cs + t);
+          }
+          float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+          if constexpr (!FAST) {
+            if (a.mask_mode != HSP_MASK_NONE && tok) mk = *reinterpret_cast<const float4*>(a.mask + (int64_t)b * a.mask_bs + t);
+          }
+          static_for<16>([&](auto rr) __attribute__((always_inline)) {
+            constexpr int r = decltype(rr)::value;
+            stage[((r & 3) + 8 * (r >> 2) + 4 * half) * ESTR + l32] = acc[i][n][r];
+          });
+          wave_lds_fence();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int co = mw + i * 32 + er + 8 * q;
+            if (tok && co < a.Cout) {
+              const float4 v = *reinterpret_cast<const float4*>(stage + (er + 8 * q) * ESTR + ec);
+              float e[4] = {v.x, v.y, v.z, v.w};
+              const float r4[4] = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
+              const float y4[4] = {yo[q].x, yo[q].y, yo[q].z, yo[q].w};
+              const float m4[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                float x = e[u] + add[q];
+                if constexpr (!FAST) {
+                  x = hsp_apply_act(x, a.act);
+                  if (a.mask_mode & HSP_MASK_PRE) x *= m4[u];
+                }
+                x = fmaf(x, cs[q], r4[u]);
+                if constexpr (!FAST) {
+                  if (a.mask_mode & HSP_MASK_POST) x *= m4[u];
+                }
+                e[u] = (x + y4[u]) * a.post_scale;
+              }
+              *reinterpret_cast<float4*>(a.y + (int64_t)b * a.y_bs + (int64_t)co * a.y_cs + t) =
+                  make_float4(e[0], e[1], e[2], e[3]);
+            }
+          }
+          wave_lds_fence();  // the staging area is rewritten by the next block
+        });
+      });
+    };
+    if (a.act == HSP_ACT_NONE && a.mask_mode == HSP_MASK_NONE && !a.cscale && !a.cbias) run(std::true_type{});
+    else run(std::false_type{});
+    return;
+  }
   if (a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU) {
     if constexpr (TM % 2 == 0) {
       const int H = a.gate_half;
-      static_for<TM / 2>([&](auto ih) {
+      static_for<TM / 2>([&](auto ih) __attribute__((always_inline)) {
         constexpr int i = 2 * decltype(ih)::value;
         const int mpair = mw + i * 32;  // packed row of the 'a' block; multiple of 64
-        static_for<TN>([&](auto nn) {
+        static_for<TN>([&](auto nn) __attribute__((always_inline)) {
           constexpr int n = decltype(nn)::value;
           const int t = tw + n * 32;
           if (mpair < a.M && t < a.ncols) {
-            static_for<16>([&](auto rr) {
+            static_for<16>([&](auto rr) __attribute__((always_inline)) {
               constexpr int r = decltype(rr)::value;
               const int co = (mpair >> 6) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
               if (co < H) {
@@ -435,13 +524,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       });
     }
   } else {
-    static_for<TM>([&](auto ii) {
+    static_for<TM>([&](auto ii) __attribute__((always_inline)) {
       constexpr int i = decltype(ii)::value;
-      static_for<TN>([&](auto nn) {
+      static_for<TN>([&](auto nn) __attribute__((always_inline)) {
         constexpr int n = decltype(nn)::value;
         const int t = tw + n * 32;
         if (t < a.ncols) {
-          static_for<16>([&](auto rr) {
+          static_for<16>([&](auto rr) __attribute__((always_inline)) {
             constexpr int r = decltype(rr)::value;
             const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             int co = m, to = t;
@@ -494,7 +583,7 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     if (l2 > lkc) lkc = l2;
   }
   if (lkc < 0) return HSP_EINVAL;
-  const int lds_bytes = make_plan<C>(a.K, a.dil, a.prologue, lkc).total * (int)sizeof(float);
+  int lds_bytes = make_plan<C>(a.K, a.dil, a.prologue, lkc).total * (int)sizeof(float);
   if (plan_out) {
     plan_out[0] = C::BM; plan_out[1] = C::BN; plan_out[2] = 1 << lkc; plan_out[3] = lds_bytes;
     return 0;
@@ -513,7 +602,15 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     if (e != hipSuccess) return (int)e;
     lds_cap.store(kMaxLdsBytes, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc);
+  // vector epilogue: plain rows and every tensor it touches 16-B addressable in float4 steps
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool epi_vec = a.rows == HSP_ROWS_PLAIN && (a.ncols & 3) == 0 && al16(a.y) && (a.y_bs & 3) == 0 &&
+                       (a.y_cs & 3) == 0 &&
+                       (!a.res || (al16(a.res) && (a.res_bs & 3) == 0 && (a.res_cs & 3) == 0)) &&
+                       (a.mask_mode == HSP_MASK_NONE || (al16(a.mask) && (a.mask_bs & 3) == 0)) && !(a.debug & 32);
+  if (lds_bytes < NCW * 32 * 36 * 4) lds_bytes = NCW * 32 * 36 * 4;  // epilogue staging area
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc,
+                     epi_vec ? 1 : 0);
   return (int)hipGetLastError();
 }
 
