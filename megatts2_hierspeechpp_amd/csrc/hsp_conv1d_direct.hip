@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void conv1d_direct_kernel(const hsp_conv1d_arg
       if (p < 0 || p >= a.Lin) continue;
       const float* wj = a.w + (int64_t)j * a.Cin * a.w_ld + co;
       const float* xp = xb + (int64_t)p * a.x_ts;
+#pragma unroll 8
       for (int ci = 0; ci < a.Cin; ++ci) {
         float xv = xp[(int64_t)ci * a.x_cs];
         if (a.prologue == HSP_PRO_LRELU) xv = xv > 0.0f ? xv : xv * a.slope;

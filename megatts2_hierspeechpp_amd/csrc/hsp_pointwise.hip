@@ -12,48 +12,100 @@ inline unsigned grid_for(int64_t n, int threads, int64_t cap = 1048576) {
 }
 
 // ---------------------------------------------------------------- Activation1d
-// One workgroup = one (b, c) row segment of TILE outputs.  The raw window, the 2x-rate
-// snake signal and the output live in LDS / registers, so HBM sees one read and one
-// write of the tensor (the eager reference makes ~38 passes).
-constexpr int ACT_TILE = 1024;
+// Stand-alone anti-aliased SnakeBeta (used where no conv follows, and -- measured faster on
+// MI355X for wide layers -- in front of a plain conv instead of the fused prologue, because
+// VALU work inside the conv kernel is paid in fp32-MFMA time on the same SIMD).
+// One workgroup = ACT_TILE outputs of one (b, c) row.  The raw window (aligned float4 loads),
+// the 2x-rate snake signal and the result go through LDS, so HBM sees one read and one write
+// of the tensor (the eager reference makes ~38 passes).
+constexpr int ACT_TILE = 2048;
 constexpr int ACT_THREADS = 256;
+constexpr int ACT_HALO = 8;  // raw window starts at p0 - 8 (16-B aligned); 5 are needed
+
+typedef float act_f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
                                                             int L, const float* __restrict__ alpha_exp,
                                                             const float* __restrict__ beta_inv,
                                                             const float* __restrict__ filt, int n_tiles) {
-  __shared__ float xr[ACT_TILE + 10];
-  __shared__ float a2[2 * ACT_TILE + 10];
+  __shared__ __attribute__((aligned(16))) float raw[ACT_TILE + 2 * ACT_HALO];
+  __shared__ __attribute__((aligned(16))) float a2[2 * ACT_TILE + 16];
   const int tile = blockIdx.x % n_tiles;
   const int row = blockIdx.x / n_tiles;  // b * C + c
   const int c = row % C;
   const int p0 = tile * ACT_TILE;
   const float* xrow = x + (int64_t)row * L;
   float* yrow = y + (int64_t)row * L;
-  float h[24];
-#pragma unroll
-  for (int i = 0; i < 24; ++i) h[i] = filt[i];
-  const float ea = alpha_exp[c], binv = beta_inv[c];
+  const float kf = alpha_exp[c] * 0.318309886183790672f, kb = 0.5f * beta_inv[c];
   const int n_out = min(ACT_TILE, L - p0);
-
-  for (int s = threadIdx.x; s < n_out + 10; s += ACT_THREADS) xr[s] = xrow[hsp_clampi(p0 - 5 + s, 0, L - 1)];
-  __syncthreads();
-  const int mlo = 2 * p0 - 5;
-  for (int s = threadIdx.x; s < 2 * n_out + 10; s += ACT_THREADS) {
-    const int m = hsp_clampi(mlo + s, 0, 2 * L - 1);
-    const int q = m >> 1, odd = m & 1;
-    const float* xp = xr + (q - 3 + odd) - (p0 - 5);
-    float u = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) u = fmaf(xp[i], odd ? h[10 - 2 * i] : h[11 - 2 * i], u);
-    a2[s] = hsp_snake(2.0f * u, ea, binv);
+  const int tid = threadIdx.x;
+  const bool vec = ((L & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  // ---- raw[s] = x[clamp(p0 - 8 + s)], s in [0, n_out + 16)
+  const int nraw = n_out + 2 * ACT_HALO;
+  if (vec && p0 >= ACT_HALO && p0 + n_out + ACT_HALO <= L) {
+    for (int v = tid; v < nraw / 4; v += ACT_THREADS)
+      *reinterpret_cast<float4*>(raw + 4 * v) = *reinterpret_cast<const float4*>(xrow + p0 - ACT_HALO + 4 * v);
+  } else {
+    for (int s = tid; s < nraw; s += ACT_THREADS) raw[s] = xrow[hsp_clampi(p0 - ACT_HALO + s, 0, L - 1)];
   }
   __syncthreads();
-  for (int s = threadIdx.x; s < n_out; s += ACT_THREADS) {
-    float v = 0.0f;
+  // ---- a2[s] = snake(2 * up[clamp(2*p0 - 5 + s)]), s in [0, 2*n_out + 10)
+  const int a2w = 2 * n_out + 10;
+  const int mlo = 2 * p0 - 5;
+  if (mlo >= 0 && mlo + a2w <= 2 * L) {
+    // interior: slot 2i+1 <-> m = 2q (q = p0-2+i), slot 2i+2 <-> m = 2q+1; x[q-3 .. q+3] = raw[i+3 .. i+9]
+    const int npair = (a2w - 1) >> 1;
+    for (int i = tid; i < npair; i += ACT_THREADS) {
+      float xv[7];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) v = fmaf(h[12 + k], a2[2 * s + k], v);
-    yrow[p0 + s] = v;
+      for (int t = 0; t < 7; ++t) xv[t] = raw[i + 3 + t];
+      act_f32x2 u = {0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const act_f32x2 xx = {xv[t], xv[t + 1]};
+        const act_f32x2 hh = {filt[11 - 2 * t], filt[10 - 2 * t]};
+        u = __builtin_elementwise_fma(xx, hh, u);
+      }
+      u = u * 2.0f;
+      a2[2 * i + 1] = hsp_snake_hw(u.x, kf, kb);
+      a2[2 * i + 2] = hsp_snake_hw(u.y, kf, kb);
+    }
+    if (tid < 2) {  // slot 0 (odd m, raw[3..8]) and the last slot (even m)
+      const float* xr_ = tid ? raw + n_out + 7 : raw + 3;
+      float uu = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) uu = fmaf(xr_[t], tid ? filt[11 - 2 * t] : filt[10 - 2 * t], uu);
+      a2[tid ? a2w - 1 : 0] = hsp_snake_hw(2.0f * uu, kf, kb);
+    }
+  } else {
+    for (int s = tid; s < a2w; s += ACT_THREADS) {
+      const int m = hsp_clampi(mlo + s, 0, 2 * L - 1);
+      const int q = m >> 1, odd = m & 1;
+      const float* xr_ = raw + (q - 3 + odd) - (p0 - ACT_HALO);
+      float u = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) u = fmaf(xr_[t], odd ? filt[10 - 2 * t] : filt[11 - 2 * t], u);
+      a2[s] = hsp_snake_hw(2.0f * u, kf, kb);
+    }
+  }
+  __syncthreads();
+  // ---- y[p0 + s] = sum_k hd[k] * a2[2s + k]
+  auto down = [&](int s) {
+    const act_f32x2* ar = reinterpret_cast<const act_f32x2*>(a2 + 2 * s);
+    act_f32x2 v = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const act_f32x2 hh = {filt[12 + 2 * k], filt[13 + 2 * k]};
+      v = __builtin_elementwise_fma(ar[k], hh, v);
+    }
+    return v.x + v.y;
+  };
+  if (vec && (n_out & 3) == 0) {
+    for (int v = tid; v < n_out / 4; v += ACT_THREADS)
+      *reinterpret_cast<float4*>(yrow + p0 + 4 * v) = make_float4(down(4 * v), down(4 * v + 1), down(4 * v + 2), down(4 * v + 3));
+  } else {
+    for (int s = tid; s < n_out; s += ACT_THREADS) yrow[p0 + s] = down(s);
   }
 }
 

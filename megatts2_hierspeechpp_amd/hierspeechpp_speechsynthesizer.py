@@ -16,6 +16,7 @@ discriminators) are not instantiated; their checkpoint keys are skipped on load.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -32,6 +33,13 @@ from .hip_layers import Conv1d, ConvTranspose1d, Linear, finalize as _finalize
 from .styleencoder import StyleEncoder
 
 UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / analysis only
+
+# Activation1d placement.  The anti-aliased activation can run as the LDS prologue of the
+# following conv (no HBM round trip) or as its own HBM-bound launch in front of a plain conv.
+# On MI355X the fp32 MFMA shares the SIMD's fp32 datapath with the VALU, so prologue arithmetic
+# is paid in MFMA time; layers with more input channels than this run the activation unfused
+# (DESIGN.md §5 has the measurements behind the default).
+FUSE_ACT_MAX_CHANNELS = int(os.environ.get("HSP_FUSE_ACT_MAX_C", "64"))
 
 
 class ResidualCouplingBlock_Transformer(nn.Module):
@@ -53,10 +61,12 @@ class ResidualCouplingBlock_Transformer(nn.Module):
         if not reverse:
             raise NotImplementedError("training direction is out of scope")
         c = self.cond_block[0](g.reshape(g.shape[0], -1), act=L.ACT_SILU)
-        c = self.cond_block[2](c)[:, :, 0]  # [B, hidden]
+        # every DiT block consumes SiLU(c) (adaLN_modulation = Sequential(SiLU, Linear)): apply it
+        # once in the epilogue of the producing Linear instead of 12 times per flow
+        c_silu = self.cond_block[2](c, act=L.ACT_SILU)[:, :, 0]  # [B, hidden]
         for i in reversed(range(self.n_flows)):
-            x = self.flows[2 * i + 1](x, x_mask, g=c, reverse=True)                 # Flip -> fresh tensor
-            x = self.flows[2 * i](x, x_mask, g=c, reverse=True, inplace=True)      # coupling, in place
+            x = self.flows[2 * i + 1](x, x_mask, reverse=True)                                  # Flip -> fresh tensor
+            x = self.flows[2 * i](x, x_mask, g=None, c_silu=c_silu, reverse=True, inplace=True)  # coupling, in place
         return x
 
 
@@ -108,11 +118,18 @@ class AMPBlock1(nn.Module):
 
     def forward(self, x, *, out=None, accumulate=False, post_scale=1.0):
         n = len(self.convs1)
+        fuse = self.convs1[0].cin <= FUSE_ACT_MAX_CHANNELS
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             last = i == n - 1
-            xt = c1(x, act1d=self.activations[2 * i])
-            x = c2(xt, act1d=self.activations[2 * i + 1], res=x, out=out if last else None,
-                   accumulate=accumulate and last, post_scale=post_scale if last else 1.0)
+            a1, a2 = self.activations[2 * i], self.activations[2 * i + 1]
+            kw = dict(res=x, out=out if last else None, accumulate=accumulate and last,
+                      post_scale=post_scale if last else 1.0)
+            if fuse:
+                xt = c1(x, act1d=a1)
+                x = c2(xt, act1d=a2, **kw)
+            else:
+                xt = c1(a1(x))
+                x = c2(a2(xt), **kw)
         return x
 
 

@@ -100,10 +100,14 @@ class DiTConVBlock(nn.Module):
         # nn.Sequential(SiLU, Linear) in the reference: index 1 carries the parameters
         self.adaLN_modulation = nn.ModuleList([nn.Identity(), Linear(hidden_size, 6 * hidden_size)])
 
-    def forward(self, x, c, x_mask):
+    def forward(self, x, c, x_mask, c_silu=None):
+        """``c_silu`` = SiLU(c) precomputed by the caller (the same for every block of a flow)."""
         C = self.hidden_size
         x = Fh.mask_mul(x, x_mask)
-        mod = self.adaLN_modulation[1](c, silu_in=True)  # [B, 6C, 1]
+        if c_silu is not None:
+            mod = self.adaLN_modulation[1](c_silu)           # [B, 6C, 1]
+        else:
+            mod = self.adaLN_modulation[1](c, silu_in=True)  # [B, 6C, 1]
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = (mod[:, i * C:(i + 1) * C, 0] for i in range(6))
         h = Fh.layernorm_mod(x, 1e-6, mask=x_mask, shift=sh_a, scale=sc_a)
         qkv = self.attn.qkv(h)
@@ -131,13 +135,13 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
                                         for _ in range(n_layers)])
         self.post = Conv1d(hidden_channels, self.half_channels, 1)
 
-    def forward(self, x, x_mask, g=None, reverse=False, inplace=False):
+    def forward(self, x, x_mask, g=None, reverse=False, inplace=False, c_silu=None):
         if not reverse:
             raise NotImplementedError("training direction (logdet) is out of scope")
         half = self.half_channels
         h = self.pre(x[:, :half], mask=x_mask, mask_mode=L.MASK_PRE)
         for blk in self.enc_block:
-            h = blk(h, g, x_mask)
+            h = blk(h, g, x_mask, c_silu=c_silu)
         out = x if inplace else x.clone()
         # x1 <- (x1 - post(h) * mask) * mask          (modules.py:473,486)
         self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, half:], out=out[:, half:])
