@@ -116,7 +116,9 @@ class AMPBlock1(nn.Module):
         self.activations = nn.ModuleList([
             Activation1d(activation=activations.SnakeBeta(channels, alpha_logscale=True)) for _ in range(self.num_layers)])
 
-    def forward(self, x, *, out=None, accumulate=False, post_scale=1.0):
+    def forward(self, x, *, out=None, accumulate=False, post_scale=1.0, before_last=None):
+        """``before_last``: an event the current stream waits on before the last launch (the one
+        that accumulates into the shared ``out`` of the stage)."""
         n = len(self.convs1)
         fuse = self.convs1[0].cin <= FUSE_ACT_MAX_CHANNELS
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
@@ -126,19 +128,61 @@ class AMPBlock1(nn.Module):
                       post_scale=post_scale if last else 1.0)
             if fuse:
                 xt = c1(x, act1d=a1)
+                if last and before_last is not None:
+                    torch.cuda.current_stream(x.device).wait_event(before_last)
                 x = c2(xt, act1d=a2, **kw)
             else:
-                xt = c1(a1(x))
-                x = c2(a2(xt), **kw)
+                xt = a2(c1(a1(x)))
+                if last and before_last is not None:
+                    torch.cuda.current_stream(x.device).wait_event(before_last)
+                x = c2(xt, **kw)
         return x
+
+
+# The parallel AMP blocks of a stage are independent chains of six launches each.  They are
+# issued on separate HIP streams so that the GPU can co-schedule them: an HBM-bound activation
+# launch of one chain runs under the MFMA-bound conv of another, and the partial last wave of
+# a conv (e.g. 448 workgroups on 256 CUs at stage 1) is back-filled.  Only the last conv of each
+# chain touches the shared accumulator; events serialise those three launches in block order,
+# so the sum is formed in the reference's order ((b0 + b1) + b2) / 3.
+AMP_STREAMS = int(os.environ.get("HSP_AMP_STREAMS", "1"))
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.type, device.index)
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 
 
 def _amp_stage(resblocks, first, num_kernels, x):
     """xs = sum_j block_j(x); x = xs / num_kernels (hierspeechpp_speechsynthesizer.py:440-446)."""
-    xs = None
+    if not AMP_STREAMS or num_kernels == 1:
+        xs = None
+        for j in range(num_kernels):
+            last = j == num_kernels - 1
+            xs = resblocks[first + j](x, out=xs, accumulate=j > 0, post_scale=(1.0 / num_kernels) if last else 1.0)
+        return xs
+    main = torch.cuda.current_stream(x.device)
+    side = _side_streams(x.device, num_kernels - 1)
+    xs = torch.empty_like(x)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    done = [torch.cuda.Event() for _ in range(num_kernels)]
     for j in range(num_kernels):
+        st = main if j == 0 else side[j - 1]
         last = j == num_kernels - 1
-        xs = resblocks[first + j](x, out=xs, accumulate=j > 0, post_scale=(1.0 / num_kernels) if last else 1.0)
+        with torch.cuda.stream(st):
+            if j > 0:
+                st.wait_event(fork)
+            gate = done[j - 1] if j > 0 else None
+            resblocks[first + j](x, out=xs, accumulate=j > 0, post_scale=(1.0 / num_kernels) if last else 1.0,
+                                 before_last=gate)
+            done[j].record(st)
+    for ev in done[1:]:
+        main.wait_event(ev)
     return xs
 
 
