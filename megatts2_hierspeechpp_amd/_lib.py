@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhsp.so")
+LIB_PATH = os.environ.get("HSP_LIB", os.path.join(_HERE, "libhsp.so"))  # HSP_LIB: kernel A/B builds
 
 # enums of include/hsp.h
 PRO_NONE, PRO_LRELU, PRO_ACT1D, PRO_SILU = 0, 1, 2, 3

@@ -37,17 +37,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int NCW = 4;    // consumer waves
 
 template <int WM, int WN, int TM, int TN, int NPW_, int MINW_>
 struct Cfg {
-  static_assert(WM * WN == NCW, "four consumer waves");
+  static constexpr int NCW = WM * WN;              // consumer waves (4, or 8 = two per SIMD)
   static constexpr int kWM = WM, kWN = WN, kTM = TM, kTN = TN;
   static constexpr int BM = WM * TM * 32;
   static constexpr int BN = WN * TN * 32;
   static constexpr int NPW = NPW_;                 // producer waves
   static constexpr int NPT = NPW_ * 64;            // producer threads
-  static constexpr int THREADS = 64 * (NCW + NPW_);
+  static constexpr int THREADS = 64 * (WM * WN + NPW_);
   static constexpr int MINW = MINW_;               // waves per SIMD the register allocation must allow
 };
 
@@ -99,6 +98,20 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+}
+
+// 32-bit LDS byte address of a pointer into the workgroup's dynamic shared memory
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+
+// N fragment registers from consecutive 32-float blocks: f[i] = lds[addr + i * 128 B]
+template <int N, int I = 0>
+__device__ __forceinline__ void ds_read_frags(float (&f)[N], unsigned addr) {
+  if constexpr (I < N) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[I]) : "v"(addr), "n"(I * 128));
+    ds_read_frags<N, I + 1>(f, addr);
+  }
 }
 
 // wave-local LDS ordering: all earlier LDS ops of this wave are complete and the
@@ -290,9 +303,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
   const int lane = threadIdx.x & 63;
   const int nchunks = (a.Cin + KC - 1) >> lkc;
 
-  if (wave >= NCW) {
+  if (wave >= C::NCW) {
     // ------------------------------------------------------------ producers
-    const int pw = wave - NCW;
+    const int pw = wave - C::NCW;
     const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
                       (int)a.x_ts, a.prologue, a.slope};
     const float* xb = a.x + (int64_t)b * a.x_bs;
@@ -361,42 +374,50 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
     const int cb = c & 1;
     const float* const ws = lds + cb * P.ws_sz + wlane;
     const float* const xs = lds + P.xa_off + cb * P.xa_sz + xlane;
-    // k-steps ordered channel-pair outer, tap inner: A += KC*BM, B += dil per step
-    const float* pa = ws;
-    const float* pb = xs;
-    int j = 0, kk = 0;
+    // k-steps ordered channel-pair outer, tap inner; the (tap, pair) -> LDS offset walk is
+    // scalar.  Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of
+    // step s+1 are issued right after the wait that retires the reads of step s and BEFORE
+    // the 8..16 MFMAs of step s, so an LDS round trip never sits between two MFMA groups
+    // (left to itself hipcc sinks the prefetch under the MFMAs and waits on it at once).
+    int offA = 0, offB = 0, j = 0, kk = 0;
+    auto advance = [&]() __attribute__((always_inline)) {
+      const bool wrap = (j + 1 == a.K);
+      kk += wrap ? 1 : 0;
+      j = wrap ? 0 : j + 1;
+      offA = wrap ? 2 * kk * BM : offA + a_step;
+      offB = wrap ? 2 * kk * P.xwp : offB + a.dil;
+    };
+    const unsigned aA = lds_addr(ws), aB = lds_addr(xs);  // per-lane LDS byte addresses
     float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_set = [&](float (&fa)[TM], float (&fb)[TN], unsigned va, unsigned vb) __attribute__((always_inline)) {
+      ds_read_frags<TM>(fa, va);
+      ds_read_frags<TN>(fb, vb);
+    };
+    auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa0[i] = pa[i * 32];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TN; ++i) fb0[i] = pb[i * 32];
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    };
+    read_set(fa0, fb0, aA, aB);
     for (int s = (a.debug & 2) ? nsteps : 0; s < nsteps; s += 2) {
-      // ---- prefetch step s+1 into set 1, multiply set 0
-      pa += a_step; pb += a.dil;
-      if (++j == a.K) { j = 0; ++kk; pa = ws + 2 * kk * BM; pb = xs + 2 * kk * P.xwp; }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa1[i] = pa[i * 32];
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fb1[i] = pb[i * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i], fb0[n], acc[i][n], 0, 0, 0);
-      // ---- prefetch step s+2 into set 0 (skipped on the last trip)
-      pa += a_step; pb += a.dil;
-      if (++j == a.K) { j = 0; ++kk; pa = ws + 2 * kk * BM; pb = xs + 2 * kk * P.xwp; }
-      if (s + 2 < nsteps) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa0[i] = pa[i * 32];
-#pragma unroll
-        for (int i = 0; i < TN; ++i) fb0[i] = pb[i * 32];
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i], fb1[n], acc[i][n], 0, 0, 0);
+      advance();  // step s+1 (always valid: nsteps is even)
+      unsigned va = aA + 4u * (unsigned)offA, vb = aB + 4u * (unsigned)offB;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(fa1, fb1, va, vb);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
+      mma_set(fa0, fb0);
+      advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
+      const bool more = s + 2 < nsteps;
+      va = aA + 4u * (unsigned)(more ? offA : 0);
+      vb = aB + 4u * (unsigned)(more ? offB : 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(fa0, fb0, va, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_set(fa1, fb1);
     }
     lds_barrier();
   }
@@ -608,7 +629,7 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
                        (a.y_cs & 3) == 0 &&
                        (!a.res || (al16(a.res) && (a.res_bs & 3) == 0 && (a.res_cs & 3) == 0)) &&
                        (a.mask_mode == HSP_MASK_NONE || (al16(a.mask) && (a.mask_bs & 3) == 0)) && !(a.debug & 32);
-  if (lds_bytes < NCW * 32 * 36 * 4) lds_bytes = NCW * 32 * 36 * 4;  // epilogue staging area
+  if (lds_bytes < C::NCW * 32 * 36 * 4) lds_bytes = C::NCW * 32 * 36 * 4;  // epilogue staging area
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc,
                      epi_vec ? 1 : 0);
   return (int)hipGetLastError();
@@ -639,6 +660,7 @@ int validate(const hsp_conv1d_args& a) {
 
 // tile shapes <WM, WN, TM, TN, producer waves, min waves per SIMD>
 using M256 = Cfg<2, 2, 4, 2, 4, 2>;    // 256 x 128, one workgroup per CU
+using M256W8 = Cfg<4, 2, 2, 2, 4, 3>;  // 256 x 128, eight consumer waves (two per SIMD)
 using M128 = Cfg<2, 2, 2, 2, 4, 2>;    // 128 x 128
 using M64 = Cfg<1, 4, 2, 2, 8, 3>;     //  64 x 256
 using M32 = Cfg<1, 4, 1, 4, 8, 3>;     //  32 x 512

@@ -146,6 +146,7 @@ class AMPBlock1(nn.Module):
 # chain touches the shared accumulator; events serialise those three launches in block order,
 # so the sum is formed in the reference's order ((b0 + b1) + b2) / 3.
 AMP_STREAMS = int(os.environ.get("HSP_AMP_STREAMS", "1"))
+FRONT_SPLITS = int(os.environ.get("HSP_FRONT_SPLITS", "4"))
 _SIDE_STREAMS = {}
 
 
@@ -318,9 +319,41 @@ class SynthesizerTrn(nn.Module):
             noise = torch.randn(stats.shape[0], C, stats.shape[2], dtype=torch.float32, device=stats.device)
         return Fh.sample_prior(stats, noise, y_mask, noise_scale)
 
-    def _decode(self, z, y_mask, g):
-        z = self.flow_l(z, y_mask, g=g, reverse=True)
-        z = self.flow(z, y_mask, g=g, reverse=True)
+    def _latent(self, w2v, f0, y_mask, g, noise, noise_scale):
+        """prior sample -> both reversed flows.  Everything here works on 50 Hz frames (a few
+        hundred columns per utterance): ~250 small, latency-bound launches.  Utterances are
+        independent, so the batch is cut into FRONT_SPLITS groups issued on separate streams;
+        their launches overlap on the GPU instead of each one draining the chip."""
+        B = w2v.shape[0]
+        n = min(FRONT_SPLITS, B)
+        if n <= 1:
+            z = self._prior(w2v, f0, y_mask, g, noise, noise_scale)
+            return self.flow(self.flow_l(z, y_mask, g=g, reverse=True), y_mask, g=g, reverse=True)
+        if noise is None:
+            noise = torch.randn(B, self.inter_channels, w2v.shape[2], dtype=torch.float32, device=w2v.device)
+        main = torch.cuda.current_stream(w2v.device)
+        side = _side_streams(w2v.device, n - 1)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        z = torch.empty(B, self.inter_channels, w2v.shape[2], dtype=torch.float32, device=w2v.device)
+        bounds = [(B * i) // n for i in range(n + 1)]
+        for i in range(n):
+            lo, hi = bounds[i], bounds[i + 1]
+            st = main if i == 0 else side[i - 1]
+            with torch.cuda.stream(st):
+                if i > 0:
+                    st.wait_event(fork)
+                zi = self._prior(w2v[lo:hi], f0[lo:hi], y_mask[lo:hi], g[lo:hi], noise[lo:hi], noise_scale)
+                zi = self.flow_l(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True)
+                zi = self.flow(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True)
+                z[lo:hi].copy_(zi)
+                if i > 0:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    main.wait_event(ev)
+        return z
+
+    def _decode(self, z, g):
         e, e_ = self.sn(z, g)
         return self.dec(z, e, g=g), e_
 
@@ -330,8 +363,8 @@ class SynthesizerTrn(nn.Module):
         randn_like draw of :202 for reproducible parity runs."""
         x_mask = commons.sequence_mask(length, x_mel.size(2))
         g = self.emb_g(x_mel, x_mask).unsqueeze(-1)
-        z = self._prior(w2v, f0, x_mask, g, noise, 1.0)
-        return self._decode(z, x_mask, g)
+        z = self._latent(w2v, f0, x_mask, g, noise, 1.0)
+        return self._decode(z, g)
 
     @torch.no_grad()
     def voice_conversion(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333, uncond=False,
@@ -342,8 +375,8 @@ class SynthesizerTrn(nn.Module):
         trg_mask = commons.sequence_mask(trg_length, trg_mel.size(2))
         g = self.emb_g(trg_mel, trg_mask).unsqueeze(-1)
         y_mask = commons.sequence_mask(src_length, src.size(2))
-        z = self._prior(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
-        return self._decode(z, y_mask, g)[0]
+        z = self._latent(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
+        return self._decode(z, g)[0]
 
     @torch.no_grad()
     def voice_conversion_noise_control(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333,
@@ -356,8 +389,8 @@ class SynthesizerTrn(nn.Module):
         g = self.emb_g(trg_mel, trg_mask)  # [2, 256]
         g = Fh.axpby(g[:1], g[1:], 1.0 - denoise_ratio, float(denoise_ratio)).unsqueeze(-1)
         y_mask = commons.sequence_mask(src_length, src.size(2))
-        z = self._prior(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
-        return self._decode(z, y_mask, g)[0]
+        z = self._latent(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
+        return self._decode(z, g)[0]
 
 
 def _f0_3d(f0):
