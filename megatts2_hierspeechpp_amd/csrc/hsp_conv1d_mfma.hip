@@ -673,10 +673,9 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   return launch<HSP_ONLY_CFG>(a, s, plan_out);
 #else
   const bool gated = a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU;
-  // "short": the whole launch offers few tiles; prefer small tiles with deep chunks so that
-  // every CU gets work and each tile sees few global-load round trips
-  const int64_t cols = (int64_t)a.B * a.ncols;
-  const bool short_seq = a.ncols <= 256 && (int64_t)((a.M + 255) / 256) * ((cols + 127) / 128) < 512;
+  // "short": even 128 x 128 tiles would leave CUs idle; prefer small tiles with deep chunks so
+  // that every CU gets work and each tile sees few global-load round trips
+  const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B < 256;
   if (short_seq) {
     if (gated) return launch<S64G>(a, s, plan_out);
     if (a.M > 32) return launch<S64>(a, s, plan_out);
