@@ -147,9 +147,20 @@ def main():
         tot_fl = sum(f for f, _, _ in mf)
         tot_b = sum(b for _, b, _ in mf)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM bytes of the same kernel from the PMC counters: measured by tools/pmc_traffic.sh (rocprofv3
+        # cannot wrap a run from inside) and committed under profiles/; only quoted for the same workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("batch_per_gpu") == B and tj.get("frames") == T:
+                traffic = tj["conv1d_mfma_bytes_per_step"] / tj["conv1d_mfma_launches_per_step"]
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {
             "kernel": "conv1d_mfma_kernel (all tile configs)", "bound": "mfma", "achieved": ach,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
+            "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
             "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
             "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,
             "hbm_frac_of_8TBs": (tot_b / (tot_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
