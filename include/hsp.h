@@ -201,6 +201,9 @@ int hsp_masked_mean_f32(const float* x, const float* mask, float* out, int32_t B
                         int32_t T, void* stream);
 /* y[b, c, t] = x[b, c, t] * mask[b, t] : the `x * x_mask` steps (modules.py:407) */
 int hsp_mask_mul_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+/* y = F.interpolate(x, Lout, mode='linear') along T (align_corners=False), fp32 index arithmetic
+ * bit-compatible with torch-CPU: speechsr48k/speechsr.py:96 */
+int hsp_linear_interp_f32(const float* x, float* y, int32_t B, int32_t C, int32_t Lin, int32_t Lout, void* stream);
 /* y = a*x + b*z elementwise (style interpolation, hierspeechpp_speechsynthesizer.py:682) */
 int hsp_axpby_f32(const float* x, const float* z, float* y, float a, float b, int64_t n, void* stream);
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "hsp_mha_f32": (C.c_int, [C.POINTER(MhaArgs), _fp]),
     "hsp_masked_mean_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_mask_mul_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_linear_interp_f32": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_axpby_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_int64, _fp]),
 }
 

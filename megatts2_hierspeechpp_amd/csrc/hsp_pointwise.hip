@@ -184,6 +184,25 @@ __global__ void mask_mul_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+// F.interpolate(mode='linear', align_corners=False) along T.  torch's CPU kernel evaluates the
+// source index in fp32 with ONE rounding, src = fmaf(scale, i + 0.5, -0.5), clamped at 0; a
+// separate mul + sub is off by 2e-3 at L = 64000 because ulp(src) ~ 4e-3 there.
+__global__ void linear_interp_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int Lin,
+                                     int Lout, float scale) {
+  const int64_t n = rows * Lout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Lout);
+    const int64_t r = i / Lout;
+    float src = fmaf(scale, (float)t + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < Lin - 1 ? 1 : 0);
+    const float l1 = src - (float)i0, l0 = 1.0f - l1;
+    const float* xr = x + r * Lin;
+    y[i] = l0 * xr[i0] + l1 * xr[i1];
+  }
+}
+
 __global__ void axpby_kernel(const float* x, const float* z, float* y, float a, float b, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + b * z[i];
@@ -316,6 +335,15 @@ extern "C" int hsp_mask_mul_f32(const float* x, const float* mask, float* y, int
   if (!x || !mask || !y || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
   hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for((int64_t)B * C * T, 256)), dim3(256), 0, HSP_STREAM, x, mask, y, B,
                      C, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_linear_interp_f32(const float* x, float* y, int32_t B, int32_t C, int32_t Lin, int32_t Lout,
+                                    void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || Lin <= 0 || Lout <= 0) return HSP_EINVAL;
+  const float scale = (float)Lin / (float)Lout;  // torch: area_pixel_compute_scale, align_corners=False
+  hipLaunchKernelGGL(linear_interp_kernel, dim3(grid_for((int64_t)B * C * Lout, 256)), dim3(256), 0, HSP_STREAM, x, y,
+                     (int64_t)B * C, Lin, Lout, scale);
   return (int)hipGetLastError();
 }
 

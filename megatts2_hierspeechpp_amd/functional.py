@@ -116,3 +116,13 @@ def axpby(x, z, a: float, b: float):
     L.check(L.lib().hsp_axpby_f32(L.fptr(x), L.fptr(z), L.fptr(y), float(a), float(b), x.numel(), L.stream_ptr()),
             "hsp_axpby_f32")
     return y
+
+
+def linear_interp(x, out_len: int):
+    """F.interpolate(x, out_len, mode='linear') along the last axis of [B, C, L]."""
+    x = _c(x)
+    B, Cc, Lin = x.shape
+    y = torch.empty(B, Cc, out_len, dtype=torch.float32, device=x.device)
+    L.check(L.lib().hsp_linear_interp_f32(L.fptr(x), L.fptr(y), B, Cc, Lin, out_len, L.stream_ptr()),
+            "hsp_linear_interp_f32")
+    return y

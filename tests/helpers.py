@@ -137,6 +137,9 @@ def build_module(meta):
                            cfg["upsample_initial_channel"], cfg["upsample_kernel_sizes"], gin_channels=256)
     if kind in ("infer", "vc"):
         return H.SynthesizerTrn(641, 61440 // 320, **cfg)
+    if kind == "speechsr":
+        from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SR
+        return SR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [meta["factor"]], 32, [3])
     raise KeyError(kind)
 
 
@@ -156,7 +159,7 @@ def run_hip(meta, arrays, device):
             kind, lambda: arrays["x"].shape[2])()
         mask = Fh.sequence_mask(d("lengths"), T)
     with torch.no_grad():
-        if kind in ("act1d", "amp_block", "convtr", "dblock"):
+        if kind in ("act1d", "amp_block", "convtr", "dblock", "speechsr"):
             out = [mod(d("x"))]
         elif kind == "wn":
             out = [mod(d("x"), mask, g=d("g"))]

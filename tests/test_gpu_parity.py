@@ -23,7 +23,7 @@ def _close(got, ref, name=""):
 
 
 # ------------------------------------------------------------------ (a) golden vectors
-@pytest.mark.parametrize("name", [n for n in H.fixture_names() if n != "speechsr48"])
+@pytest.mark.parametrize("name", H.fixture_names())
 def test_golden(name, device):
     meta, arrays = H.load_fixture(name)
     outs = H.run_hip(meta, arrays, device)
@@ -125,6 +125,18 @@ def test_wn_and_attention_longer_ragged(device):
         ref = O.dit_conv_block({"d." + k: v for k, v in sd.items()}, "d", x.transpose(1, 2), c,
                                mask_c.transpose(1, 2)).transpose(1, 2).numpy()
     _close(got, ref, "dit T=333")
+
+
+def test_linear_interp_long_sequence_matches_torch_cpu(device):
+    """SpeechSR's x3 linear interpolation at the full 4-s length: torch-CPU evaluates the source
+    index with a single-rounding fp32 FMA; mul+sub is off by 2e-3 on white noise at L = 64000
+    (SURVEY.md §8a A15).  Also the x1.5 factor of speechsr24k."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    x = torch.randn(2, 3, 64000, generator=torch.Generator().manual_seed(4))
+    for out_len in (192000, 96000):
+        ref = torch.nn.functional.interpolate(x, out_len, mode="linear").numpy()
+        got = Fh.linear_interp(x.to(device), out_len).cpu().numpy()
+        assert np.abs(got - ref).max() < 1e-5
 
 
 # --------------------------------------------------- (c) properties at the full size

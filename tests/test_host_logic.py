@@ -20,8 +20,6 @@ def test_state_dict_keys_match_reference():
     (captured from the reference's own state_dict by tools/make_golden.py)."""
     for name in H.fixture_names():
         meta, _ = H.load_fixture(name)
-        if meta["kind"] == "speechsr":
-            continue
         mod = H.build_module(meta)
         mine = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
         ref = {k: tuple(s) for k, s in meta["shapes"]}

@@ -19,8 +19,6 @@ dev = torch.device("cuda:0")
 bad = 0
 for n in names:
     meta, arrays = Hh.load_fixture(n)
-    if meta["kind"] == "speechsr":
-        continue
     try:
         t0 = time.time()
         outs = Hh.run_hip(meta, arrays, dev)
