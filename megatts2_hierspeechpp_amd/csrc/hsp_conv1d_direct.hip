@@ -25,12 +25,29 @@ __global__ __launch_bounds__(256) void conv1d_direct_kernel(const hsp_conv1d_arg
       if (p < 0 || p >= a.Lin) continue;
       const float* wj = a.w + (int64_t)j * a.Cin * a.w_ld + co;
       const float* xp = xb + (int64_t)p * a.x_ts;
-#pragma unroll 8
-      for (int ci = 0; ci < a.Cin; ++ci) {
-        float xv = xp[(int64_t)ci * a.x_cs];
-        if (a.prologue == HSP_PRO_LRELU) xv = xv > 0.0f ? xv : xv * a.slope;
-        else if (a.prologue == HSP_PRO_SILU) xv = xv * hsp_sigmoid(xv);
-        acc = fmaf(wj[(int64_t)ci * a.w_ld], xv, acc);
+      if (a.prologue == HSP_PRO_NONE) {
+        // independent loads, 8 in flight: a "Linear on the style vector" is a pure latency chain otherwise
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        int ci = 0;
+        for (; ci + 8 <= a.Cin; ci += 8) {
+          float wv[8], xv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            wv[u] = wj[(int64_t)(ci + u) * a.w_ld];
+            xv[u] = xp[(int64_t)(ci + u) * a.x_cs];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc4[u & 3] = fmaf(wv[u], xv[u], acc4[u & 3]);
+        }
+        for (; ci < a.Cin; ++ci) acc4[0] = fmaf(wj[(int64_t)ci * a.w_ld], xp[(int64_t)ci * a.x_cs], acc4[0]);
+        acc += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+      } else {
+        for (int ci = 0; ci < a.Cin; ++ci) {
+          float xv = xp[(int64_t)ci * a.x_cs];
+          if (a.prologue == HSP_PRO_LRELU) xv = xv > 0.0f ? xv : xv * a.slope;
+          else if (a.prologue == HSP_PRO_SILU) xv = xv * hsp_sigmoid(xv);
+          acc = fmaf(wj[(int64_t)ci * a.w_ld], xv, acc);
+        }
       }
     }
     float v = acc;

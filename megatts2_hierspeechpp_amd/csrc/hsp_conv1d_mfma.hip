@@ -69,7 +69,7 @@ __host__ __device__ inline LdsPlan make_plan(int K, int dil, int prologue, int l
   p.kc = 1 << lkc;
   p.rpw = (p.kc + C::NPW - 1) / C::NPW;
   p.xw = C::BN + (K - 1) * dil;
-  p.xwp = (p.xw + 63) & ~63;
+  p.xwp = (p.xw + 3 + 63) & ~63;  // +3: the 16-B window DMA starts at the aligned position below p0
   p.xrw = p.xw + 10;
   p.xrwp = (p.xrw + 63) & ~63;
   p.a2w = 2 * p.xw + 10;
@@ -178,6 +178,23 @@ struct Prod {
       }
     }
   }
+  // same with 16-B lanes: the window starts at p0a = p0 rounded down to a multiple of 4 and the
+  // tensor is 16-B addressable with Lin % 4 == 0, so every 4-group is fully inside or outside
+  static __device__ __forceinline__ void dma_x16(const ProdArgs& a, const LdsPlan& P, float* Xa, const float* xb,
+                                                 int c0, int p0a, int pw, int lane) {
+    const int ngrp = (P.xw + 3 + 3) >> 2;
+    for (int kc = pw; kc < P.kc; kc += C::NPW) {
+      const int ci = c0 + kc;
+      const float* xc = xb + ci * a.x_cs;
+      for (int g0 = 0; g0 < ngrp; g0 += 64) {
+        const int g = g0 + lane, p = p0a + 4 * g;
+        if (g < ngrp) {
+          const float* src = (ci < a.Cin && p >= 0 && p < a.Lin) ? xc + p : a.zeros;
+          dma16(src, Xa + kc * P.xwp + 4 * g0);
+        }
+      }
+    }
+  }
   static __device__ __forceinline__ void lrelu_x(const ProdArgs& a, const LdsPlan& P, float* Xa, int pw, int lane) {
     for (int kc = pw; kc < P.kc; kc += C::NPW)
       for (int s = lane; s < P.xwp; s += 64) {
@@ -283,7 +300,7 @@ struct Prod {
 template <class C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
                                                                  const int n_nt, const int lkc,
-                                                                 const int epi_vec) {
+                                                                 const int epi_vec, const int xvec) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = C::BM, BN = C::BN, TM = C::kTM, TN = C::kTN;
   const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
@@ -313,8 +330,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
     float* const Ws0 = lds;
     float* const Xa0 = lds + P.xa_off;
     if (a.prologue != HSP_PRO_ACT1D) {
+      const int p0a = p0 & ~3;
       PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
-      PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
+      if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
       wait_vm0();
       if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
       lds_barrier();
@@ -322,7 +340,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
         const int nb = (c + 1) & 1;
         if (c + 1 < nchunks && !(a.debug & 1)) {
           PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
-          PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
+          if (xvec) PR::dma_x16(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0a, pw, lane);
+          else PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
           wait_vm0();
           if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
         }
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int wlane = half * BM + wm * (TM * 32) + l32;
-  const int xlane = half * P.xwp + wn * (TN * 32) + l32;
+  const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? (p0 & 3) : 0);
   const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4
   const int a_step = KC * BM;          // next tap, same channel pair
 
@@ -545,6 +564,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       });
     }
   } else {
+    const float up_inv = a.rows == HSP_ROWS_SHUFFLE ? 1.0f / (float)a.up : 1.0f;
     static_for<TM>([&](auto ii) __attribute__((always_inline)) {
       constexpr int i = decltype(ii)::value;
       static_for<TN>([&](auto nn) __attribute__((always_inline)) {
@@ -557,7 +577,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
             int co = m, to = t;
             bool ok = m < a.M;
             if (a.rows == HSP_ROWS_SHUFFLE) {
-              co = m / a.up;
+              co = (int)(((float)m + 0.5f) * up_inv);  // m / up, exact for m < 2^22 (no integer divide)
               to = a.up * t + (m - co * a.up) - a.shuf_pad;
               ok = ok && to >= 0 && to < a.Lout;
             }
@@ -630,8 +650,11 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
                        (!a.res || (al16(a.res) && (a.res_bs & 3) == 0 && (a.res_cs & 3) == 0)) &&
                        (a.mask_mode == HSP_MASK_NONE || (al16(a.mask) && (a.mask_bs & 3) == 0)) && !(a.debug & 32);
   if (lds_bytes < C::NCW * 32 * 36 * 4) lds_bytes = C::NCW * 32 * 36 * 4;  // epilogue staging area
+  // 16-B window DMA: plain prologue on a 16-B addressable input whose length is a multiple of 4
+  const bool xvec = a.prologue != HSP_PRO_ACT1D && a.x_ts == 1 && (a.Lin & 3) == 0 && (a.x_cs & 3) == 0 &&
+                    (a.x_bs & 3) == 0 && al16(a.x) && !(a.debug & 64);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc,
-                     epi_vec ? 1 : 0);
+                     epi_vec ? 1 : 0, xvec ? 1 : 0);
   return (int)hipGetLastError();
 }
 
@@ -651,7 +674,7 @@ int validate(const hsp_conv1d_args& a) {
   if (a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU) {
     if (a.gate_half <= 0 || (a.gate_half & 31) || a.M != 2 * a.gate_half || a.Cout != a.gate_half) return HSP_EINVAL;
   } else if (a.rows == HSP_ROWS_SHUFFLE) {
-    if (a.up <= 0 || a.M != a.Cout * a.up) return HSP_EINVAL;
+    if (a.up <= 0 || a.up > 16 || a.M != a.Cout * a.up || a.M > (1 << 16)) return HSP_EINVAL;
   } else if (a.rows != HSP_ROWS_PLAIN) {
     return HSP_EINVAL;
   }
