@@ -618,11 +618,12 @@ int pick_lkc(const hsp_conv1d_args& a, int lds_limit) {
 
 template <class C>
 int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
-  int lkc = pick_lkc<C>(a, kLdsTarget);
-  if (lkc < 3) {
-    const int l2 = pick_lkc<C>(a, kMaxLdsBytes);
-    if (l2 > lkc) lkc = l2;
-  }
+  // a shape whose register budget admits two workgroups per CU keeps its LDS under half the
+  // CU's; the others take the deepest chunk the whole 160 KB can stage (fewer barriers, and the
+  // DMA of a chunk gets a longer MFMA phase to land under)
+  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS;
+  int lkc = pick_lkc<C>(a, two_per_cu ? kLdsTarget : kMaxLdsBytes);
+  if (lkc < 0) lkc = pick_lkc<C>(a, kMaxLdsBytes);
   if (lkc < 0) return HSP_EINVAL;
   int lds_bytes = make_plan<C>(a.K, a.dil, a.prologue, lkc).total * (int)sizeof(float);
   if (plan_out) {
@@ -684,7 +685,7 @@ int validate(const hsp_conv1d_args& a) {
 // tile shapes <WM, WN, TM, TN, producer waves, min waves per SIMD>
 using M256 = Cfg<2, 2, 4, 2, 4, 2>;    // 256 x 128, one workgroup per CU
 using M256W8 = Cfg<4, 2, 2, 2, 4, 3>;  // 256 x 128, eight consumer waves (two per SIMD)
-using M128 = Cfg<2, 2, 2, 2, 4, 2>;    // 128 x 128
+using M128 = Cfg<2, 2, 2, 2, 4, 4>;    // 128 x 128, two workgroups per CU
 using M64 = Cfg<1, 4, 2, 2, 8, 3>;     //  64 x 256
 using M32 = Cfg<1, 4, 1, 4, 8, 3>;     //  32 x 512
 using S64 = Cfg<2, 2, 1, 1, 4, 2>;     //  64 x 64   short sequences: many small, deep-chunk tiles
