@@ -137,6 +137,121 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32-MFMA attention (v_mfma_f32_32x32x2_f32, exact fp32) for the no-window case: timm
+// Attention of the DiT blocks and the StyleEncoder's self-attention.  One workgroup = 32
+// queries of one (batch, head):
+//   S^T-free layout: S[32 x Tk] = (scale*Q)^T K  with M = queries, N = keys, k = head dim
+//                    (A fragments from the Q tile in LDS, B fragments straight from the
+//                    channel-major K plane: 32 consecutive keys per half wave);
+//   row softmax in LDS (mask -> -1e4 exactly like attentions.py:175);
+//   O^T[D x 32] = V P^T with M = head dim, N = queries, k = keys: V is staged through LDS in
+//                    64-key slabs (odd pitch: the column reads of both operands are conflict
+//                    free) and the result lands with queries on the lanes -> coalesced stores.
+constexpr int MQT = 32;
+typedef float mha_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int n_qt, int sp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = a.D, Tq = a.Tq, Tk = a.Tk;
+  const int DP = (D + 31) & ~31;
+  float* Qs = lds;                 // [DP][32]  scale * q, zero rows beyond D
+  float* S = Qs + DP * 32;         // [32][sp]
+  float* Vs = S + 32 * sp;         // [DP][65]
+  int bid = blockIdx.x;
+  const int qt = bid % n_qt;
+  bid /= n_qt;
+  const int h = bid % a.H;
+  const int b = bid / a.H;
+  const int i0 = qt * MQT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * Tq;
+  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * Tk;
+  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * Tk;
+  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * Tq;
+
+  for (int e = tid; e < DP * 32; e += 256) {
+    const int i = e & 31, d = e >> 5;
+    Qs[e] = (d < D && i0 + i < Tq) ? qh[(int64_t)d * Tq + i0 + i] * a.qk_scale : 0.0f;
+  }
+  __syncthreads();
+
+  // ---- scores: wave w owns key blocks w, w+4, ...
+  const int nkb = (Tk + 31) >> 5;
+  const int d2 = DP >> 1;
+  for (int jb = wave; jb < nkb; jb += 4) {
+    mha_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int j = jb * 32 + l32;
+    const bool jok = j < Tk;
+#pragma unroll 4
+    for (int kk = 0; kk < d2; ++kk) {
+      const int d = 2 * kk + half;
+      const float av = Qs[d * 32 + l32];
+      const float bv = (jok && d < D) ? kh[(int64_t)d * Tk + j] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * half) * sp + j] = acc[r];
+  }
+  __syncthreads();
+
+  // ---- row softmax over the Tk valid keys (8 rows per wave); padding columns become 0
+  for (int u = 0; u < 8; ++u) {
+    const int row_i = wave * 8 + u;
+    float* row = S + row_i * sp;
+    const int i = i0 + row_i;
+    const float mq = (a.mask_q && i < Tq) ? a.mask_q[(int64_t)b * Tq + i] : 1.0f;
+    float mx = -3.0e38f;
+    for (int j = lane; j < Tk; j += 64) {
+      float sv = row[j];
+      if (a.mask_q && mq * a.mask_k[(int64_t)b * Tk + j] == 0.0f) sv = -1e4f;
+      row[j] = sv;
+      mx = fmaxf(mx, sv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int j = lane; j < Tk; j += 64) {
+      const float e = expf(row[j] - mx);
+      row[j] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < nkb * 32 + 32 && j < sp; j += 64) row[j] = j < Tk ? row[j] * inv : 0.0f;
+  }
+
+  // ---- O^T = V P^T: wave w owns head-dim block w (D <= 128)
+  mha_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int ndb = DP >> 5;
+  for (int j0 = 0; j0 < Tk; j0 += 64) {
+    __syncthreads();  // softmax complete (first slab) / previous slab consumed
+    for (int d = wave; d < DP; d += 4)
+      Vs[d * 65 + lane] = (d < D && j0 + lane < Tk) ? vh[(int64_t)d * Tk + j0 + lane] : 0.0f;
+    __syncthreads();
+    if (wave < ndb) {
+      const float* va = Vs + (wave * 32 + l32) * 65 + half;
+      const float* pb = S + l32 * sp + j0 + half;
+#pragma unroll 8
+      for (int jj = 0; jj < 64; jj += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[jj], pb[jj], acc, 0, 0, 0);
+    }
+  }
+  if (wave < ndb && i0 + l32 < Tq) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (d < D) oh[(int64_t)d * Tq + i0 + l32] = acc[r];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
@@ -145,6 +260,25 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   if (!a.q || !a.k || !a.v || !a.o || a.B <= 0 || a.H <= 0 || a.D <= 0 || a.Tq <= 0 || a.Tk <= 0) return HSP_EINVAL;
   if ((a.mask_q == nullptr) != (a.mask_k == nullptr)) return HSP_EINVAL;
   if ((a.rel_k || a.rel_v) && (a.window <= 0 || a.Tq != a.Tk)) return HSP_EINVAL;
+  // matrix-core path: no relative-position window, head dim <= 128, scores of 32 queries fit LDS
+  if (!a.rel_k && !a.rel_v && a.D <= 128) {
+    const int DP = (a.D + 31) & ~31;
+    const int sp = ((a.Tk + 31) & ~31) + 33;  // odd pitch, room for one zero slab column block
+    const int64_t lds_m = ((int64_t)DP * 32 + 32 * (int64_t)sp + (int64_t)DP * 65) * (int64_t)sizeof(float);
+    if (lds_m <= 160 * 1024) {
+      static std::atomic<int> cap{32 * 1024};
+      if (lds_m > cap.load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        cap.store(160 * 1024, std::memory_order_relaxed);
+      }
+      const int n_qt32 = (a.Tq + MQT - 1) / MQT;
+      hipLaunchKernelGGL(mha_mfma_kernel, dim3((unsigned)((int64_t)n_qt32 * a.H * a.B)), dim3(256), (size_t)lds_m,
+                         static_cast<hipStream_t>(stream), a, n_qt32, sp);
+      return (int)hipGetLastError();
+    }
+  }
   const int n_qt = (a.Tq + QT - 1) / QT;
   const int dpad = (a.D < 128 ? a.D : 128) | 1;
   const int spad = a.Tk + 1;
