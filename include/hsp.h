@@ -131,10 +131,8 @@ typedef struct hsp_conv1d_args {
   int64_t res_bs, res_cs;
   int32_t accumulate;
   float post_scale;
-  int32_t debug; /* 0 in production.  Tuning aids: bit 0 = producers stage only the first chunk,
-                    bit 1 = consumers skip their MFMAs, bits 2-4 = skip activation / weight DMA /
-                    epilogue (results are then WRONG); bit 5/6 = force the scalar epilogue / 4-B
-                    window DMA, bit 8 = persistent grid (results unchanged) */
+  int32_t debug; /* 0 in production.  Tuning aids (results are then WRONG): bit 0 = producers
+                    stage only the first chunk, bit 1 = consumers skip their MFMAs */
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) implicit-GEMM path; stride must be 1,

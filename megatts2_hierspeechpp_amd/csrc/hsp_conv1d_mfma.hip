@@ -59,7 +59,7 @@ struct LdsPlan {
   int xrwp;     // raw row pitch in the producer scratch (multiple of 64)
   int a2w;      // 2x-rate window width    = 2*xw + 10      (ACT1D)
   int ws_sz, xa_sz, scr_sz;  // floats: one weight slab, one window buffer, one producer scratch
-  int xa_off, scr_off, epi_off, total;
+  int xa_off, scr_off, total;
 };
 
 template <class C>
@@ -79,8 +79,7 @@ __host__ __device__ inline LdsPlan make_plan(int K, int dil, int prologue, int l
   p.scr_sz = prologue == HSP_PRO_ACT1D ? 2 * p.rpw * p.xrwp + ((p.a2w + 3) & ~3) : 0;
   p.xa_off = 2 * p.ws_sz;
   p.scr_off = p.xa_off + 2 * p.xa_sz;
-  p.epi_off = p.scr_off + C::NPW * p.scr_sz;   // consumers' epilogue transpose area (the producers are
-  p.total = p.epi_off + C::NCW * 32 * 36;      // already staging the next tile while it is in use)
+  p.total = p.scr_off + C::NPW * p.scr_sz;
   return p;
 }
 
@@ -307,57 +306,44 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
   const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
   const int KC = P.kc;
 
-  // PERSISTENT tile loop.  Workgroup g owns tiles g, g + gridDim.x, ...; tile index =
-  // mt + n_mt * (nt + n_nt * b): row tiles fastest, so the workgroups that round-robin onto one
-  // XCD keep hitting the same weight slab in that XCD's L2.  Producers and consumers walk the
-  // same flat list of (tile, chunk) items with one barrier per item, so the producers stage the
-  // first chunk of the NEXT tile under the last chunk and the epilogue of the current one: no
-  // pipeline fill / drain per tile, and no tail of half-empty CUs.
+  // blockIdx.x = mt + n_mt * (nt + n_nt * b): row tiles fastest, so the blocks that
+  // round-robin onto one XCD keep hitting the same weight slab in that XCD's L2.
+  int bid = blockIdx.x;
+  const int mt = bid % n_mt;
+  bid /= n_mt;
+  const int nt = bid % n_nt;
+  const int b = bid / n_nt;
+  const int m0 = mt * BM, t0 = nt * BN;
+  const int p0 = t0 - a.pad;  // first activated-input position of the window
+
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int nchunks = (a.Cin + KC - 1) >> lkc;
-  const int ntiles = n_mt * n_nt * a.B;
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int nitems = my_tiles * nchunks;
-  struct TileC { int b, m0, t0; };
-  auto tile_of = [&](int k) __attribute__((always_inline)) {
-    int t = (int)blockIdx.x + k * (int)gridDim.x;
-    const int mt = t % n_mt;
-    t /= n_mt;
-    return TileC{t / n_nt, mt * BM, (t % n_nt) * BN};
-  };
 
   if (wave >= C::NCW) {
     // ------------------------------------------------------------ producers
     const int pw = wave - C::NCW;
     const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
                       (int)a.x_ts, a.prologue, a.slope};
+    const float* xb = a.x + (int64_t)b * a.x_bs;
     using PR = Prod<C>;
     float* const Ws0 = lds;
     float* const Xa0 = lds + P.xa_off;
-    // item cursor of the producers (item = tile k, chunk c)
-    struct Cur { int k, c; TileC t; };
-    auto next = [&](Cur u) __attribute__((always_inline)) {
-      if (++u.c == nchunks) { u.c = 0; ++u.k; u.t = tile_of(u.k); }
-      return u;
-    };
     if (a.prologue != HSP_PRO_ACT1D) {
-      auto stage = [&](const Cur& u, int buf) __attribute__((always_inline)) {
-        const float* xb = a.x + (int64_t)u.t.b * a.x_bs;
-        const int p0 = u.t.t0 - a.pad;
-        PR::dma_w(pa, P, Ws0 + buf * P.ws_sz, u.c << lkc, u.t.m0, pw, lane);
-        if (xvec) PR::dma_x16(pa, P, Xa0 + buf * P.xa_sz, xb, u.c << lkc, p0 & ~3, pw, lane);
-        else PR::dma_x(pa, P, Xa0 + buf * P.xa_sz, xb, u.c << lkc, p0, pw, lane);
-        wait_vm0();
-        if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + buf * P.xa_sz, pw, lane);
-      };
-      Cur cur{0, 0, tile_of(0)};
-      stage(cur, 0);
+      const int p0a = p0 & ~3;
+      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
+      if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
+      wait_vm0();
+      if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
       lds_barrier();
-      for (int w = 0; w < nitems; ++w) {
-        if (w + 1 < nitems) {
-          cur = next(cur);
-          if (!(a.debug & 1)) stage(cur, (w + 1) & 1);
+      for (int c = 0; c < nchunks; ++c) {
+        const int nb = (c + 1) & 1;
+        if (c + 1 < nchunks && !(a.debug & 1)) {
+          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
+          if (xvec) PR::dma_x16(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0a, pw, lane);
+          else PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
+          wait_vm0();
+          if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
         }
         lds_barrier();
       }
@@ -365,28 +351,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       float* const scr = lds + P.scr_off + pw * P.scr_sz;   // raw[2][rpw][xrwp], a2[a2w]
       float* const a2 = scr + 2 * P.rpw * P.xrwp;
       const int rsz = P.rpw * P.xrwp;
-      auto raw = [&](const Cur& u, int rb) __attribute__((always_inline)) {
-        PR::dma_raw(pa, P, scr + rb * rsz, a.x + (int64_t)u.t.b * a.x_bs, u.c << lkc, u.t.t0 - a.pad, pw, lane);
-      };
-      auto act = [&](const Cur& u, int buf) __attribute__((always_inline)) {
-        PR::act_rows(pa, P, scr + buf * rsz, a2, Xa0 + buf * P.xa_sz, u.c << lkc, u.t.t0 - a.pad, pw, lane);
-      };
-      Cur cur{0, 0, tile_of(0)};       // item being activated / published next
-      raw(cur, 0);
-      PR::dma_w(pa, P, Ws0, 0, cur.t.m0, pw, lane);
+      PR::dma_raw(pa, P, scr, xb, 0, p0, pw, lane);
+      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
       wait_vm0();
-      act(cur, 0);
-      Cur ahead = cur;                  // item whose raw rows are in flight
-      if (nitems > 1) { ahead = next(cur); raw(ahead, 1); }
+      PR::act_rows(pa, P, scr, a2, Xa0, 0, p0, pw, lane);
+      if (nchunks > 1) PR::dma_raw(pa, P, scr + rsz, xb, KC, p0, pw, lane);
       wait_vm0();
       lds_barrier();
-      for (int w = 0; w < nitems; ++w) {
-        if (w + 1 < nitems && !(a.debug & 1)) {
-          const int nb = (w + 1) & 1;
-          cur = ahead;                  // item w + 1: its raw rows landed before the last barrier
-          if (!(a.debug & 8)) PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, cur.c << lkc, cur.t.m0, pw, lane);
-          if (w + 2 < nitems) { ahead = next(cur); raw(ahead, w & 1); }
-          if (!(a.debug & 4)) act(cur, nb);
+      for (int c = 0; c < nchunks; ++c) {
+        const int nb = (c + 1) & 1;
+        if (c + 1 < nchunks && !(a.debug & 1)) {
+          if (!(a.debug & 8)) PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
+          if (c + 2 < nchunks) PR::dma_raw(pa, P, scr + (c & 1) * rsz, xb, (c + 2) << lkc, p0, pw, lane);
+          if (!(a.debug & 4)) PR::act_rows(pa, P, scr + nb * rsz, a2, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0, pw, lane);
           wait_vm0();
         }
         lds_barrier();
@@ -407,11 +384,63 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int wlane = half * BM + wm * (TM * 32) + l32;
-  const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? ((-a.pad) & 3) : 0);
+  const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? (p0 & 3) : 0);
   const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4
   const int a_step = KC * BM;          // next tap, same channel pair
 
-  auto epilogue = [&](const int b, const int m0, const int t0) __attribute__((always_inline)) {
+  lds_barrier();  // chunk 0 staged
+  for (int c = 0; c < nchunks; ++c) {
+    const int cb = c & 1;
+    const float* const ws = lds + cb * P.ws_sz + wlane;
+    const float* const xs = lds + P.xa_off + cb * P.xa_sz + xlane;
+    // k-steps ordered channel-pair outer, tap inner; the (tap, pair) -> LDS offset walk is
+    // scalar.  Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of
+    // step s+1 are issued right after the wait that retires the reads of step s and BEFORE
+    // the 8..16 MFMAs of step s, so an LDS round trip never sits between two MFMA groups
+    // (left to itself hipcc sinks the prefetch under the MFMAs and waits on it at once).
+    int offA = 0, offB = 0, j = 0, kk = 0;
+    auto advance = [&]() __attribute__((always_inline)) {
+      const bool wrap = (j + 1 == a.K);
+      kk += wrap ? 1 : 0;
+      j = wrap ? 0 : j + 1;
+      offA = wrap ? 2 * kk * BM : offA + a_step;
+      offB = wrap ? 2 * kk * P.xwp : offB + a.dil;
+    };
+    const unsigned aA = lds_addr(ws), aB = lds_addr(xs);  // per-lane LDS byte addresses
+    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_set = [&](float (&fa)[TM], float (&fb)[TN], unsigned va, unsigned vb) __attribute__((always_inline)) {
+      ds_read_frags<TM>(fa, va);
+      ds_read_frags<TN>(fb, vb);
+    };
+    auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    };
+    read_set(fa0, fb0, aA, aB);
+    for (int s = (a.debug & 2) ? nsteps : 0; s < nsteps; s += 2) {
+      advance();  // step s+1 (always valid: nsteps is even)
+      unsigned va = aA + 4u * (unsigned)offA, vb = aB + 4u * (unsigned)offB;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(fa1, fb1, va, vb);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
+      mma_set(fa0, fb0);
+      advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
+      const bool more = s + 2 < nsteps;
+      va = aA + 4u * (unsigned)(more ? offA : 0);
+      vb = aB + 4u * (unsigned)(more ? offB : 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(fa0, fb0, va, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_set(fa1, fb1);
+    }
+    lds_barrier();
+  }
+
   // ---- epilogue.  C/D map of the 32x32 forms: col = lane & 31,
   //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   // static_for keeps every accumulator index a compile-time constant: a runtime index
@@ -428,7 +457,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
     // and spill-free body; a scratch reload or a late constant load inside this loop would
     // wait on vmcnt, which also drains every older store.
     constexpr int ESTR = 36;
-    float* const stage = lds + P.epi_off + wave * (32 * ESTR);
+    float* const stage = lds + wave * (32 * ESTR);
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto run = [&](auto fast_tag) __attribute__((always_inline)) {
@@ -565,75 +594,6 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       });
     });
   }
-  };
-
-  lds_barrier();  // item 0 staged
-  int tk = 0, c = 0;
-  for (int w = 0; w < nitems; ++w) {
-    if (c == 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    }
-    const int cb = w & 1;
-    const float* const ws = lds + cb * P.ws_sz + wlane;
-    const float* const xs = lds + P.xa_off + cb * P.xa_sz + xlane;
-    // k-steps ordered channel-pair outer, tap inner; the (tap, pair) -> LDS offset walk is
-    // scalar.  Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of
-    // step s+1 are issued right after the wait that retires the reads of step s and BEFORE
-    // the 8..16 MFMAs of step s, so an LDS round trip never sits between two MFMA groups
-    // (left to itself hipcc sinks the prefetch under the MFMAs and waits on it at once).
-    int offA = 0, offB = 0, j = 0, kk = 0;
-    auto advance = [&]() __attribute__((always_inline)) {
-      const bool wrap = (j + 1 == a.K);
-      kk += wrap ? 1 : 0;
-      j = wrap ? 0 : j + 1;
-      offA = wrap ? 2 * kk * BM : offA + a_step;
-      offB = wrap ? 2 * kk * P.xwp : offB + a.dil;
-    };
-    const unsigned aA = lds_addr(ws), aB = lds_addr(xs);  // per-lane LDS byte addresses
-    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto read_set = [&](float (&fa)[TM], float (&fb)[TN], unsigned va, unsigned vb) __attribute__((always_inline)) {
-      ds_read_frags<TM>(fa, va);
-      ds_read_frags<TN>(fb, vb);
-    };
-    auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
-    };
-    read_set(fa0, fb0, aA, aB);
-    for (int s = (a.debug & 2) ? nsteps : 0; s < nsteps; s += 2) {
-      advance();  // step s+1 (always valid: nsteps is even)
-      unsigned va = aA + 4u * (unsigned)offA, vb = aB + 4u * (unsigned)offB;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
-      __builtin_amdgcn_sched_barrier(0);
-      read_set(fa1, fb1, va, vb);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
-      mma_set(fa0, fb0);
-      advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
-      const bool more = s + 2 < nsteps;
-      va = aA + 4u * (unsigned)(more ? offA : 0);
-      vb = aB + 4u * (unsigned)(more ? offB : 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
-      __builtin_amdgcn_sched_barrier(0);
-      read_set(fa0, fb0, va, vb);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_set(fa1, fb1);
-    }
-    lds_barrier();
-    if (++c == nchunks) {
-      const TileC tc = tile_of(tk);
-      epilogue(tc.b, tc.m0, tc.t0);
-      c = 0;
-      ++tk;
-    }
-  }
 }
 
 // -------------------------------------------------------------------- host side
@@ -672,25 +632,8 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   }
   const int n_mt = (a.M + C::BM - 1) / C::BM;
   const int n_nt = (a.ncols + C::BN - 1) / C::BN;
-  const int64_t ntiles = (int64_t)n_mt * n_nt * a.B;
-  if (ntiles <= 0 || ntiles > 0x7fffffff) return HSP_EINVAL;
-  // persistent grid: as many workgroups as can be resident (registers: MINW; LDS: 160 KB per CU),
-  // each looping over its share of the tiles
-  static const int n_cu = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-  }();
-  int per_cu = (C::MINW * 256) / C::THREADS;
-  if (per_cu < 1) per_cu = 1;
-  const int by_lds = kMaxLdsBytes / lds_bytes;
-  if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
-  // One tile per workgroup by default: measured on the full pipeline (three AMP chains on
-  // separate streams) the hardware dispatcher's staggering and back-filling beat a persistent
-  // grid by ~1 %; alone on the GPU the persistent grid (debug bit 8 of the second byte) wins
-  // 5-20 % on stage-1 and low-channel shapes.
-  int64_t blocks = ntiles;
-  if ((a.debug & 256) && (int64_t)n_cu * per_cu < ntiles) blocks = (int64_t)n_cu * per_cu;
+  const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
+  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
   auto kern = conv1d_mfma_kernel<C>;
   // raise the kernel's dynamic-LDS cap once (idempotent; kept out of the launch path
   // afterwards so that launches are legal inside a hipGraph stream capture)
@@ -707,6 +650,7 @@ int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
                        (a.y_cs & 3) == 0 &&
                        (!a.res || (al16(a.res) && (a.res_bs & 3) == 0 && (a.res_cs & 3) == 0)) &&
                        (a.mask_mode == HSP_MASK_NONE || (al16(a.mask) && (a.mask_bs & 3) == 0)) && !(a.debug & 32);
+  if (lds_bytes < C::NCW * 32 * 36 * 4) lds_bytes = C::NCW * 32 * 36 * 4;  // epilogue staging area
   // 16-B window DMA: plain prologue on a 16-B addressable input whose length is a multiple of 4
   const bool xvec = a.prologue != HSP_PRO_ACT1D && a.x_ts == 1 && (a.Lin & 3) == 0 && (a.x_cs & 3) == 0 &&
                     (a.x_bs & 3) == 0 && al16(a.x) && !(a.debug & 64);
