@@ -563,6 +563,39 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
         });
       });
     }
+  } else if (a.rows == HSP_ROWS_SHUFFLE && a.act == HSP_ACT_NONE && a.mask_mode == HSP_MASK_NONE && !a.cscale &&
+             !a.cbias && !a.res && !a.accumulate) {
+    // ConvTranspose fast path: row m = co*up + phase writes y[co, up*t + phase - pad].  Row
+    // constants (channel, phase, bias, row pointer) are resolved once per accumulator row; the
+    // store loop has no loads, so nothing ever waits on vmcnt.  The `up` stores of one channel
+    // (registers r&3 for up = 4, r&1 for up = 2) interleave into full lines in L2.
+    const float up_inv = 1.0f / (float)a.up;
+    static_for<TM>([&](auto ii) __attribute__((always_inline)) {
+      constexpr int i = decltype(ii)::value;
+      float* yrow[16];
+      float bz[16];
+      int toff[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = (int)(((float)m + 0.5f) * up_inv);
+        const bool ok = m < a.M && co < a.Cout;
+        toff[r] = ok ? (m - co * a.up) - a.shuf_pad : -(1 << 30);
+        yrow[r] = a.y + (int64_t)b * a.y_bs + (int64_t)(ok ? co : 0) * a.y_cs;
+        bz[r] = (ok && a.bias) ? a.bias[co] : 0.0f;
+      }
+      static_for<TN>([&](auto nn) __attribute__((always_inline)) {
+        constexpr int n = decltype(nn)::value;
+        const int t = tw + n * 32;
+        if (t < a.ncols) {
+          static_for<16>([&](auto rr) __attribute__((always_inline)) {
+            constexpr int r = decltype(rr)::value;
+            const int to = a.up * t + toff[r];
+            if (to >= 0 && to < a.Lout) yrow[r][to] = (acc[i][n][r] + bz[r]) * a.scale * a.post_scale;
+          });
+        }
+      });
+    });
   } else {
     const float up_inv = a.rows == HSP_ROWS_SHUFFLE ? 1.0f / (float)a.up : 1.0f;
     static_for<TM>([&](auto ii) __attribute__((always_inline)) {

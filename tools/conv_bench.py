@@ -22,6 +22,7 @@ ap.add_argument("--act", type=int, default=1)
 ap.add_argument("--res", type=int, default=0)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--debug", type=int, default=0)
+ap.add_argument("--actonly", type=int, default=0, help="time the stand-alone activation kernel instead")
 a = ap.parse_args()
 hip_layers.DEBUG_FLAGS = a.debug
 dev = torch.device("cuda:0")
@@ -44,7 +45,7 @@ hip_layers.finalize(m, dev)
 x = torch.randn(a.batch, a.cin, a.len, device=dev)
 res = torch.randn(a.batch, a.cout, a.len, device=dev) if a.res else None
 out = torch.empty(a.batch, a.cout, a.len, device=dev)
-run = lambda: m.conv(x, act1d=m.act if a.act else None, res=res, out=out)
+run = (lambda: m.act(x)) if a.actonly else (lambda: m.conv(x, act1d=m.act if a.act else None, res=res, out=out))
 for _ in range(3):
     run()
 torch.cuda.synchronize()
@@ -56,4 +57,8 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 fl = 2.0 * a.batch * a.cout * a.cin * a.k * a.len
+if a.actonly:
+    gb = 8.0 * a.batch * a.cin * a.len / 1e9
+    print(f"act1d C {a.cin} L {a.len} B {a.batch}: {ms*1e3:9.1f} us  {gb/ms*1e3:7.1f} GB/s")
+    sys.exit(0)
 print(f"cin {a.cin} cout {a.cout} k {a.k} dil {a.dil} L {a.len} B {a.batch} act {a.act} dbg {a.debug}: {ms*1e3:9.1f} us  {fl/ms/1e9:7.2f} TF/s")
