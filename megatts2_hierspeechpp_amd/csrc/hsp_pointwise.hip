@@ -18,7 +18,7 @@ inline unsigned grid_for(int64_t n, int threads, int64_t cap = 1048576) {
 // One workgroup = ACT_TILE outputs of one (b, c) row.  The raw window (aligned float4 loads),
 // the 2x-rate snake signal and the result go through LDS, so HBM sees one read and one write
 // of the tensor (the eager reference makes ~38 passes).
-constexpr int ACT_TILE = 2048;
+constexpr int ACT_TILE = 1024;
 constexpr int ACT_THREADS = 256;
 constexpr int ACT_HALO = 8;  // raw window starts at p0 - 8 (16-B aligned); 5 are needed
 
@@ -54,22 +54,33 @@ __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const float* __restr
   const int a2w = 2 * n_out + 10;
   const int mlo = 2 * p0 - 5;
   if (mlo >= 0 && mlo + a2w <= 2 * L) {
-    // interior: slot 2i+1 <-> m = 2q (q = p0-2+i), slot 2i+2 <-> m = 2q+1; x[q-3 .. q+3] = raw[i+3 .. i+9]
+    // interior: slot 2i+1 <-> m = 2q (q = p0-2+i), slot 2i+2 <-> m = 2q+1; x[q-3 .. q+3] = raw[i+3 .. i+9].
+    // Two adjacent pairs per thread share their raw window (8 LDS reads for 4 outputs).
     const int npair = (a2w - 1) >> 1;
-    for (int i = tid; i < npair; i += ACT_THREADS) {
-      float xv[7];
+    float hu[12];
 #pragma unroll
-      for (int t = 0; t < 7; ++t) xv[t] = raw[i + 3 + t];
-      act_f32x2 u = {0.0f, 0.0f};
+    for (int t = 0; t < 12; ++t) hu[t] = filt[t];
+    for (int i = 2 * tid; i < npair; i += 2 * ACT_THREADS) {
+      float xv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xv[t] = raw[i + 3 + t];
+      act_f32x2 u0 = {0.0f, 0.0f}, u1 = {0.0f, 0.0f};
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
-        const act_f32x2 xx = {xv[t], xv[t + 1]};
-        const act_f32x2 hh = {filt[11 - 2 * t], filt[10 - 2 * t]};
-        u = __builtin_elementwise_fma(xx, hh, u);
+        const act_f32x2 hh = {hu[11 - 2 * t], hu[10 - 2 * t]};
+        const act_f32x2 x0 = {xv[t], xv[t + 1]};
+        const act_f32x2 x1 = {xv[t + 1], xv[t + 2]};
+        u0 = __builtin_elementwise_fma(x0, hh, u0);
+        u1 = __builtin_elementwise_fma(x1, hh, u1);
       }
-      u = u * 2.0f;
-      a2[2 * i + 1] = hsp_snake_hw(u.x, kf, kb);
-      a2[2 * i + 2] = hsp_snake_hw(u.y, kf, kb);
+      u0 = u0 * 2.0f;
+      u1 = u1 * 2.0f;
+      a2[2 * i + 1] = hsp_snake_hw(u0.x, kf, kb);
+      a2[2 * i + 2] = hsp_snake_hw(u0.y, kf, kb);
+      if (i + 1 < npair) {
+        a2[2 * i + 3] = hsp_snake_hw(u1.x, kf, kb);
+        a2[2 * i + 4] = hsp_snake_hw(u1.y, kf, kb);
+      }
     }
     if (tid < 2) {  // slot 0 (odd m, raw[3..8]) and the last slot (even m)
       const float* xr_ = tid ? raw + n_out + 7 : raw + 3;
@@ -91,21 +102,40 @@ __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const float* __restr
   }
   __syncthreads();
   // ---- y[p0 + s] = sum_k hd[k] * a2[2s + k]
-  auto down = [&](int s) {
-    const act_f32x2* ar = reinterpret_cast<const act_f32x2*>(a2 + 2 * s);
-    act_f32x2 v = {0.0f, 0.0f};
+  float hd[12];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const act_f32x2 hh = {filt[12 + 2 * k], filt[13 + 2 * k]};
-      v = __builtin_elementwise_fma(ar[k], hh, v);
-    }
-    return v.x + v.y;
-  };
+  for (int t = 0; t < 12; ++t) hd[t] = filt[12 + t];
   if (vec && (n_out & 3) == 0) {
-    for (int v = tid; v < n_out / 4; v += ACT_THREADS)
-      *reinterpret_cast<float4*>(yrow + p0 + 4 * v) = make_float4(down(4 * v), down(4 * v + 1), down(4 * v + 2), down(4 * v + 3));
+    // four consecutive outputs per thread: their 12-tap windows overlap in 18 a2 values
+    for (int v = tid; v < n_out / 4; v += ACT_THREADS) {
+      const act_f32x2* ar = reinterpret_cast<const act_f32x2*>(a2 + 8 * v);
+      act_f32x2 w[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w[k] = ar[k];
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        act_f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const act_f32x2 hh = {hd[2 * k], hd[2 * k + 1]};
+          acc = __builtin_elementwise_fma(w[q + k], hh, acc);
+        }
+        o[q] = acc.x + acc.y;
+      }
+      *reinterpret_cast<float4*>(yrow + p0 + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   } else {
-    for (int s = tid; s < n_out; s += ACT_THREADS) yrow[p0 + s] = down(s);
+    for (int s = tid; s < n_out; s += ACT_THREADS) {
+      const act_f32x2* ar = reinterpret_cast<const act_f32x2*>(a2 + 2 * s);
+      act_f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const act_f32x2 hh = {hd[2 * k], hd[2 * k + 1]};
+        acc = __builtin_elementwise_fma(ar[k], hh, acc);
+      }
+      yrow[p0 + s] = acc.x + acc.y;
+    }
   }
 }
 
