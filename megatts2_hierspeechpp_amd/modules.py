@@ -9,9 +9,34 @@ from torch import nn
 
 from . import _lib as L
 from . import functional as Fh
-from .hip_layers import Conv1d, Linear
+from .hip_layers import Conv1d, HipLayer, Linear
 
 LRELU_SLOPE = 0.1  # modules.py:17
+
+
+class LayerNorm(HipLayer):
+    """modules.LayerNorm (modules.py:19-31): affine LayerNorm over the channel axis of [B, C, T]."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self.gamma = nn.Parameter(torch.ones(channels), requires_grad=False)
+        self.beta = nn.Parameter(torch.zeros(channels), requires_grad=False)
+        self._g = self._b = None
+
+    def hsp_requests(self):
+        return [("g", self.channels), ("b", self.channels)]
+
+    def hsp_fill(self, arena, materialize):
+        self._g, self._b = arena.view(self, "g"), arena.view(self, "b")
+        if materialize:
+            self._g.copy_(self.gamma.data)
+            self._b.copy_(self.beta.data)
+
+    def forward(self, x):
+        if self._g is None:
+            raise L.HspError("LayerNorm used before finalize()")
+        return Fh.layernorm_mod(x, self.eps, gamma=self._g, beta=self._b)
 
 
 class WN(nn.Module):

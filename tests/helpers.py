@@ -71,6 +71,11 @@ def run_oracle(meta, arrays):
         return [O.conv_transpose1d(sd, name, t("x"), meta["u"], (meta["k"] - meta["u"]) // 2)]
     if kind == "dblock":
         return [O.dblock(sd, name, t("x"))]
+    if kind == "rel_mha":
+        am = mask.unsqueeze(2) * mask.unsqueeze(-1)
+        return [O.mha_relpos(sd, name, t("x"), t("x"), am, meta["heads"], meta["window"])]
+    if kind == "vits_encoder":
+        return [O.vits_encoder(sd, name, t("x"), mask, meta["heads"], meta["layers"], meta["k"], meta["window"])]
     if kind == "wn":
         return [O.wavenet(sd, name, t("x"), mask, t("g"), meta["hidden"], meta["k"], meta["n_layers"])]
     if kind == "dit_block":
@@ -92,6 +97,12 @@ def run_oracle(meta, arrays):
     if kind == "vc":
         return [O.synth_voice_conversion_noise_control(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"),
                                                        t("f0"), meta["noise_scale"], meta["denoise_ratio"], t("noise"))]
+    if kind == "rel_mha":
+        from megatts2_hierspeechpp_amd import attentions
+        return attentions.MultiHeadAttention(256, 256, meta["heads"], window_size=meta["window"])
+    if kind == "vits_encoder":
+        from megatts2_hierspeechpp_amd import attentions
+        return attentions.Encoder(256, 1024, meta["heads"], meta["layers"], kernel_size=meta["k"], window_size=meta["window"])
     if kind == "speechsr":
         return [O.speechsr(sd, t("x"), meta["factor"], name + ".dec")]
     raise KeyError(kind)
@@ -137,6 +148,12 @@ def build_module(meta):
                            cfg["upsample_initial_channel"], cfg["upsample_kernel_sizes"], gin_channels=256)
     if kind in ("infer", "vc"):
         return H.SynthesizerTrn(641, 61440 // 320, **cfg)
+    if kind == "rel_mha":
+        from megatts2_hierspeechpp_amd import attentions
+        return attentions.MultiHeadAttention(256, 256, meta["heads"], window_size=meta["window"])
+    if kind == "vits_encoder":
+        from megatts2_hierspeechpp_amd import attentions
+        return attentions.Encoder(256, 1024, meta["heads"], meta["layers"], kernel_size=meta["k"], window_size=meta["window"])
     if kind == "speechsr":
         from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SR
         return SR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [meta["factor"]], 32, [3])
@@ -163,6 +180,10 @@ def run_hip(meta, arrays, device):
             out = [mod(d("x"))]
         elif kind == "wn":
             out = [mod(d("x"), mask, g=d("g"))]
+        elif kind == "rel_mha":
+            out = [mod(d("x"), d("x"), mask_q=mask, mask_k=mask)]
+        elif kind == "vits_encoder":
+            out = [mod(d("x"), mask)]
         elif kind == "dit_block":
             out = [mod(d("x").transpose(1, 2).contiguous(), d("c"), mask).transpose(1, 2)]
         elif kind == "coupling":

@@ -211,6 +211,26 @@ def main():
         save(name, dict(kind="flow", prefix=name, seed=W, shapes=shapes), dict(x=x, g=g, lengths=lengths),
              mod(t(x), mask, g=t(g), reverse=True), O.flow_reverse(sd, name, t(x), mask, t(g)))
 
+        # -- A16: relative-position MHA (T below and above the window) and a 2-layer VITS Encoder
+        import attentions as ATT
+        for Tq, lens_ in [(3, [3, 2]), (50, [50, 37])]:
+            name = f"rel_mha_t{Tq}"
+            mod = ATT.MultiHeadAttention(256, 256, 4, window_size=4)
+            shapes, sd = load_synth(mod, W, name + ".")
+            ln_ = np.array(lens_, np.int64)
+            mk = O.sequence_mask(t(ln_), Tq).unsqueeze(1).float()
+            xq = rnd(64 + Tq, 2, 256, Tq) * mk.numpy()
+            am = mk.unsqueeze(2) * mk.unsqueeze(-1)
+            save(name, dict(kind="rel_mha", prefix=name, seed=W, shapes=shapes, window=4, heads=4),
+                 dict(x=xq, lengths=ln_), mod(t(xq), t(xq), attn_mask=am),
+                 O.mha_relpos(sd, name, t(xq), t(xq), am, 4, 4))
+        name = "vits_encoder"
+        mod = ATT.Encoder(256, 1024, 4, 2, kernel_size=9, p_dropout=0.1, window_size=4)
+        shapes, sd = load_synth(mod, W, name + ".")
+        xe = rnd(66, 2, 256, T)
+        save(name, dict(kind="vits_encoder", prefix=name, seed=W, shapes=shapes, heads=4, layers=2, k=9, window=4),
+             dict(x=xe, lengths=lengths), mod(t(xe), mask), O.vits_encoder(sd, name, t(xe), mask, 4, 2, 9, 4))
+
         # -- A13: StyleEncoder
         name = "style_encoder"
         mod = StyleEncoder(in_dim=80, hidden_dim=256, out_dim=256)
