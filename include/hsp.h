@@ -194,6 +194,9 @@ typedef struct hsp_mha_args {
   const float* rel_k;
   const float* rel_v;
   int32_t window;
+  int64_t q_cs, k_cs, v_cs, o_cs; /* channel strides; 0 = contiguous rows (Tq / Tk).  A larger stride lets the
+                                     utterances of a batch sit side by side on the column axis of one
+                                     [C][B*T] matrix (batch stride T): the layout of the PLM loop */
 } hsp_mha_args;
 int hsp_mha_f32(const hsp_mha_args* a, void* stream);
 /* out[b, c] = sum_t x[b, c, t] / sum_t mask[b, t] : styleencoder.py:83-91 */
@@ -206,6 +209,27 @@ int hsp_mask_mul_f32(const float* x, const float* mask, float* y, int32_t B, int
 int hsp_linear_interp_f32(const float* x, float* y, int32_t B, int32_t C, int32_t Lin, int32_t Lout, void* stream);
 /* y = a*x + b*z elementwise (style interpolation, hierspeechpp_speechsynthesizer.py:682) */
 int hsp_axpby_f32(const float* x, const float* z, float* y, float a, float b, int64_t n, void* stream);
+
+
+/* -------------------------------------------------- Mega-TTS2 PLM loop */
+/* x[b, c, j] = cat(tc[b, :, j], emb[codes[b, j]])[c] + alpha[0] * pe_t[c, j] for j < n :
+ * the body of Megatts2PLM1.infer up to pos_emb (ttv_v1/t2w2v_transformer.py:710-713) with
+ * SinePositionalEmbedding.forward (:510-514).  tc is channel-major with strides (tc_bs, tc_cs, 1);
+ * codes is int64 [B, >= n] with row stride codes_bs and holds the go token at column 0;
+ * pe_t is the sinusoid table transposed to [Dtc + Demb][P]; x has strides (x_bs, x_cs, 1):
+ * (n, B*n) lays the batch side by side on the columns of one [D][B*n] matrix. */
+int hsp_plm_embed_f32(const float* tc, int64_t tc_bs, int64_t tc_cs, int32_t Dtc, const int64_t* codes,
+                      int64_t codes_bs, const float* emb, int32_t Demb, int32_t n_emb, const float* pe_t,
+                      int32_t P, const float* alpha, float* x, int64_t x_bs, int64_t x_cs, int32_t B, int32_t n,
+                      void* stream);
+/* out[b * out_bs] = argmax_c logits[b * l_bs + c * l_cs], first maximal index on ties :
+ * logits.argmax(dim=-1) of the greedy loop (ttv_v1/t2w2v_transformer.py:716-717) */
+int hsp_argmax_f32(const float* logits, int64_t l_bs, int64_t l_cs, int32_t B, int32_t N, int64_t* out,
+                   int64_t out_bs, void* stream);
+/* y[b, c, t] (contiguous) = x[b * s_bs + c * s_cs + t * s_ts] : strided gather, e.g. the last
+ * position of every utterance (`[:, -1:, :]`, ttv_v1/t2w2v_transformer.py:716) */
+int hsp_copy_strided_f32(const float* x, int64_t s_bs, int64_t s_cs, int64_t s_ts, float* y, int32_t B,
+                         int32_t C, int32_t T, void* stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ class MhaArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
         ("qk_scale", C.c_float),
         ("mask_q", _fp), ("mask_k", _fp), ("rel_k", _fp), ("rel_v", _fp), ("window", C.c_int32),
+        ("q_cs", C.c_int64), ("k_cs", C.c_int64), ("v_cs", C.c_int64), ("o_cs", C.c_int64),
     ]
 
 
@@ -77,6 +78,11 @@ SIGNATURES = {
     "hsp_mask_mul_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_linear_interp_f32": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_axpby_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_int64, _fp]),
+    "hsp_plm_embed_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int32, C.c_int32,
+                                    _fp, C.c_int32, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp]),
+    "hsp_argmax_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64, _fp]),
+    "hsp_copy_strided_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32,
+                                       _fp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -30,15 +30,16 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
   const int i0 = qt * QT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = a.D, Tq = a.Tq, Tk = a.Tk;
-  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * Tq;
-  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * Tk;
-  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * Tk;
-  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * Tq;
+  const int64_t qcs = a.q_cs, kcs = a.k_cs, vcs = a.v_cs, ocs = a.o_cs;  // channel strides (host fills the defaults)
+  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * qcs;
+  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * kcs;
+  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
+  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
 
   // ---- Q tile, pre-scaled (attentions.py:164 divides the query; timm scales the product)
   for (int e = tid; e < D * QT; e += ATT_THREADS) {
     const int i = e % QT, d = e / QT;
-    Qs[e] = (i0 + i < Tq) ? qh[(int64_t)d * Tq + i0 + i] * a.qk_scale : 0.0f;
+    Qs[e] = (i0 + i < Tq) ? qh[(int64_t)d * qcs + i0 + i] * a.qk_scale : 0.0f;
   }
   __syncthreads();
 
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
     for (int j = lane; j < Tk; j += 64) {
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       for (int d = 0; d < D; ++d) {
-        const float kv = kh[(int64_t)d * Tk + j];
+        const float kv = kh[(int64_t)d * kcs + j];
         const float4 qv = *reinterpret_cast<const float4*>(Qs + d * QT + iq);
         s0 = fmaf(qv.x, kv, s0);
         s1 = fmaf(qv.y, kv, s1);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
     for (int j0 = 0; j0 < Tk; j0 += 64) {
       __syncthreads();  // softmax rows complete (first pass) / previous slab consumed
       for (int dd = wave; dd < 128 && d0 + dd < D; dd += 4)
-        Vs[lane * dpad + dd] = (j0 + lane < Tk) ? vh[(int64_t)(d0 + dd) * Tk + j0 + lane] : 0.0f;
+        Vs[lane * dpad + dd] = (j0 + lane < Tk) ? vh[(int64_t)(d0 + dd) * vcs + j0 + lane] : 0.0f;
       __syncthreads();
       if (d0 + d < D) {
         const int jn = min(64, Tk - j0);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
             if (j >= 0 && j < Tk) v = fmaf(S[(ig * 8 + u) * spad + j], a.rel_v[(int64_t)(r + a.window) * D + d0 + d], v);
           }
         }
-        oh[(int64_t)(d0 + d) * Tq + i] = v;
+        oh[(int64_t)(d0 + d) * ocs + i] = v;
       }
     }
   }
@@ -166,14 +167,15 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
   const int i0 = qt * MQT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, half = lane >> 5;
-  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * Tq;
-  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * Tk;
-  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * Tk;
-  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * Tq;
+  const int64_t qcs = a.q_cs, kcs = a.k_cs, vcs = a.v_cs, ocs = a.o_cs;  // channel strides (host fills the defaults)
+  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * qcs;
+  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * kcs;
+  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
+  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
 
   for (int e = tid; e < DP * 32; e += 256) {
     const int i = e & 31, d = e >> 5;
-    Qs[e] = (d < D && i0 + i < Tq) ? qh[(int64_t)d * Tq + i0 + i] * a.qk_scale : 0.0f;
+    Qs[e] = (d < D && i0 + i < Tq) ? qh[(int64_t)d * qcs + i0 + i] * a.qk_scale : 0.0f;
   }
   __syncthreads();
 
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
     for (int kk = 0; kk < d2; ++kk) {
       const int d = 2 * kk + half;
       const float av = Qs[d * 32 + l32];
-      const float bv = (jok && d < D) ? kh[(int64_t)d * Tk + j] : 0.0f;
+      const float bv = (jok && d < D) ? kh[(int64_t)d * kcs + j] : 0.0f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
   for (int j0 = 0; j0 < Tk; j0 += 64) {
     __syncthreads();  // softmax complete (first slab) / previous slab consumed
     for (int d = wave; d < DP; d += 4)
-      Vs[d * 65 + lane] = (d < D && j0 + lane < Tk) ? vh[(int64_t)d * Tk + j0 + lane] : 0.0f;
+      Vs[d * 65 + lane] = (d < D && j0 + lane < Tk) ? vh[(int64_t)d * vcs + j0 + lane] : 0.0f;
     __syncthreads();
     if (wave < ndb) {
       const float* va = Vs + (wave * 32 + l32) * 65 + half;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (d < D) oh[(int64_t)d * Tq + i0 + l32] = acc[r];
+      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = acc[r];
     }
   }
 }
@@ -256,7 +258,12 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
 
 extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   if (!ap) return HSP_EINVAL;
-  const hsp_mha_args& a = *ap;
+  hsp_mha_args a = *ap;
+  if (a.q_cs == 0) a.q_cs = a.Tq;
+  if (a.k_cs == 0) a.k_cs = a.Tk;
+  if (a.v_cs == 0) a.v_cs = a.Tk;
+  if (a.o_cs == 0) a.o_cs = a.Tq;
+  if (a.q_cs < a.Tq || a.k_cs < a.Tk || a.v_cs < a.Tk || a.o_cs < a.Tq) return HSP_EINVAL;
   if (!a.q || !a.k || !a.v || !a.o || a.B <= 0 || a.H <= 0 || a.D <= 0 || a.Tq <= 0 || a.Tk <= 0) return HSP_EINVAL;
   if ((a.mask_q == nullptr) != (a.mask_k == nullptr)) return HSP_EINVAL;
   if ((a.rel_k || a.rel_v) && (a.window <= 0 || a.Tq != a.Tk)) return HSP_EINVAL;

@@ -282,6 +282,67 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
   }
 }
 
+// Register-resident variant for C <= 16 * LN_R: a workgroup owns 16 time columns, its 256 threads
+// are 16 columns x 16 channel groups and every thread keeps its <= LN_R channel values in
+// registers, so the tile is read once with all loads in flight (the loop kernel above chases
+// C/4 dependent loads three times: ~40 us for C = 276 whatever T is).  Short sequences still
+// give B * T/16 workgroups.
+constexpr int LN_R = 24;
+__global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                            int T, float eps, const float* __restrict__ mask,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ scale, int64_t mod_bs,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int n_tt) {
+  __shared__ float red[16][17];
+  const int tt = blockIdx.x % n_tt, b = blockIdx.x / n_tt;
+  const int lt = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const int t = tt * 16 + lt;
+  const bool live = t < T;
+  const float* xb = x + (int64_t)b * C * T + t;
+  float* yb = y + (int64_t)b * C * T + t;
+  float v[LN_R];
+#pragma unroll
+  for (int r = 0; r < LN_R; ++r) {
+    const int c = cg + 16 * r;
+    v[r] = (live && c < C) ? xb[(int64_t)c * T] : 0.0f;
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int r = 0; r < LN_R; ++r) s += v[r];
+  red[cg][lt] = s;
+  __syncthreads();
+  float tot = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) tot += red[g][lt];
+  const float mean = tot / (float)C;
+  __syncthreads();
+  float ss = 0.0f;
+#pragma unroll
+  for (int r = 0; r < LN_R; ++r) {
+    const float d = (cg + 16 * r < C) ? v[r] - mean : 0.0f;
+    ss = fmaf(d, d, ss);
+  }
+  red[cg][lt] = ss;
+  __syncthreads();
+  tot = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) tot += red[g][lt];
+  const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+  if (!live) return;
+  const float mk = mask ? mask[(int64_t)b * T + t] : 1.0f;
+#pragma unroll
+  for (int r = 0; r < LN_R; ++r) {
+    const int c = cg + 16 * r;
+    if (c >= C) break;
+    float o = (v[r] - mean) * rstd;
+    if (gamma) o = o * gamma[c] + beta[c];
+    o *= mk;
+    if (scale) o = o * (1.0f + scale[(int64_t)b * mod_bs + c]) + shift[(int64_t)b * mod_bs + c];
+    yb[(int64_t)c * T] = o;
+  }
+}
+
 // out[b, c] = sum_t x[b, c, t] / sum_t mask[b, t]; one wave per (b, c)
 __global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                                           float* __restrict__ out, int B, int C, int T) {
@@ -388,6 +449,12 @@ extern "C" int hsp_layernorm_mod_f32(const float* x, float* y, int32_t B, int32_
                                      const float* gamma, const float* beta, void* stream) {
   if (!x || !y || B <= 0 || C <= 0 || T <= 0) return HSP_EINVAL;
   if ((shift == nullptr) != (scale == nullptr) || (gamma == nullptr) != (beta == nullptr)) return HSP_EINVAL;
+  if (C <= 16 * LN_R) {
+    const int n_t16 = (T + 15) / 16;
+    hipLaunchKernelGGL(layernorm_reg_kernel, dim3((unsigned)(n_t16 * B)), dim3(256), 0, HSP_STREAM, x, y, C, T, eps,
+                       mask, shift, scale, mod_bs, gamma, beta, n_t16);
+    return (int)hipGetLastError();
+  }
   const int n_tt = (T + 63) / 64;
   hipLaunchKernelGGL(layernorm_mod_kernel, dim3((unsigned)(n_tt * B)), dim3(256), 0, HSP_STREAM, x, y, C, T, eps, mask,
                      shift, scale, mod_bs, gamma, beta, n_tt);

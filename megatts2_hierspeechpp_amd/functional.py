@@ -72,16 +72,20 @@ def layernorm_mod(x, eps: float, mask=None, shift=None, scale=None, gamma=None, 
     return y
 
 
-def mha(q, k, v, n_heads: int, qk_scale: float, mask_q=None, mask_k=None, rel_k=None, rel_v=None, window=0):
-    """q [B, H*D, Tq], k/v [B, H*D, Tk] (views with contiguous rows) -> [B, H*D, Tq]."""
+def mha(q, k, v, n_heads: int, qk_scale: float, mask_q=None, mask_k=None, rel_k=None, rel_v=None, window=0,
+        out=None):
+    """q [B, H*D, Tq], k/v [B, H*D, Tk] (any batch / channel strides, unit time stride) -> [B, H*D, Tq].
+    Strided views let a batch live side by side on the column axis of one [C, B*T] matrix
+    (``x.view(C, B, T).permute(1, 0, 2)``), the layout of the PLM loop."""
     B, HD, Tq = q.shape
     Tk = k.shape[2]
-    for t_, T_ in ((q, Tq), (k, Tk), (v, Tk)):
-        assert t_.stride(2) == 1 and t_.stride(1) == T_, "attention operands need contiguous [C, T] planes"
-    o = torch.empty(B, HD, Tq, dtype=torch.float32, device=q.device)
+    o = torch.empty(B, HD, Tq, dtype=torch.float32, device=q.device) if out is None else out
+    for t_, T_ in ((q, Tq), (k, Tk), (v, Tk), (o, Tq)):
+        assert (t_.stride(2) == 1 or T_ == 1) and t_.stride(1) >= T_, "attention operands need unit time stride"
     a = L.MhaArgs()
     a.q, a.k, a.v, a.o = L.fptr(q), L.fptr(k), L.fptr(v), L.fptr(o)
     a.q_bs, a.k_bs, a.v_bs, a.o_bs = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    a.q_cs, a.k_cs, a.v_cs, a.o_cs = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
     a.B, a.H, a.D, a.Tq, a.Tk = B, n_heads, HD // n_heads, Tq, Tk
     a.qk_scale = float(qk_scale)
     if mask_q is not None:
@@ -125,4 +129,13 @@ def linear_interp(x, out_len: int):
     y = torch.empty(B, Cc, out_len, dtype=torch.float32, device=x.device)
     L.check(L.lib().hsp_linear_interp_f32(L.fptr(x), L.fptr(y), B, Cc, Lin, out_len, L.stream_ptr()),
             "hsp_linear_interp_f32")
+    return y
+
+
+def copy_strided(x):
+    """Contiguous copy of a strided [B, C, T] view (one launch, no torch arithmetic)."""
+    B, Cc, T = x.shape
+    y = torch.empty(B, Cc, T, dtype=torch.float32, device=x.device)
+    L.check(L.lib().hsp_copy_strided_f32(L.fptr(x), x.stride(0), x.stride(1), x.stride(2), L.fptr(y), B, Cc, T,
+                                         L.stream_ptr()), "hsp_copy_strided_f32")
     return y

@@ -166,6 +166,7 @@ class _ConvBase(HipLayer):
         else:
             self.weight = nn.Parameter(torch.zeros(*weight_shape), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(bias), requires_grad=False) if bias else None
+        self.has_bias = bool(bias)
         self.wn = weight_norm
         self._w: Optional[torch.Tensor] = None
         self._b: Optional[torch.Tensor] = None
@@ -174,6 +175,9 @@ class _ConvBase(HipLayer):
         if self.wn:
             return _fold(self.weight_v.data, self.weight_g.data)
         return self.weight.data.contiguous()
+
+    def _bias_src(self) -> torch.Tensor:
+        return self.bias.data
 
     def _require_ready(self):
         if self._w is None:
@@ -196,15 +200,15 @@ class Conv1d(_ConvBase):
         self.M = int(self.row_map.shape[0])
 
     def hsp_requests(self):
-        return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.bias is not None else [])
+        return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias else [])
 
     def hsp_fill(self, arena, materialize):
         self._w = arena.view(self, "w")
-        self._b = arena.view(self, "b") if self.bias is not None else None
+        self._b = arena.view(self, "b") if self.has_bias else None
         if materialize:
             _gather(self._folded(), conv_pack_map(self.cout, self.cin, self.k, self.row_map), self._w)
             if self._b is not None:
-                self._b.copy_(self.bias.data)
+                self._b.copy_(self._bias_src())
 
     # ----------------------------------------------------------------------------
     def forward(self, x, *, act1d=None, lrelu: Optional[float] = None, silu_in=False, act=L.ACT_NONE, cbias=None,
@@ -311,6 +315,40 @@ class Linear(Conv1d):
     def forward(self, x, **kw):
         x3 = x.reshape(x.shape[0], self.cin, 1)
         return super().forward(x3, force_direct=True, **kw)
+
+
+class LinearCT(Conv1d):
+    """torch.nn.Linear applied along the channel axis of a channel-major [B, C, T] tensor (a 1x1
+    conv on the MFMA path).  ``packed=False`` keeps only the parameters (nn.Linear names and
+    shapes) for a layer whose rows are packed into a :class:`StackedLinearCT`."""
+
+    def __init__(self, cin, cout, bias=True, packed=True):
+        super().__init__(cin, cout, 1, bias=bias, weight_2d=True)
+        self.packed = packed
+
+    def hsp_requests(self):
+        return super().hsp_requests() if self.packed else []
+
+    def hsp_fill(self, arena, materialize):
+        if self.packed:
+            super().hsp_fill(arena, materialize)
+
+
+class StackedLinearCT(Conv1d):
+    """Several nn.Linear layers reading the same input, run as ONE GEMM with their output rows
+    stacked (q/k/v projections of transformer_mega.MultiHeadAttention, ttv_v1/transformer_mega.py:54-56).
+    Owns no parameters: the packed weight is gathered from the parts' ``weight`` / ``bias``."""
+
+    def __init__(self, parts):
+        super().__init__(parts[0].cin, sum(p.cout for p in parts), 1, bias=True, weight_2d=True)
+        del self._parameters["weight"], self._parameters["bias"]
+        self.__dict__["_parts"] = tuple(parts)  # not registered as sub-modules (no duplicate state_dict keys)
+
+    def _folded(self):
+        return torch.cat([p.weight.data for p in self._parts], 0).contiguous()
+
+    def _bias_src(self):
+        return torch.cat([p.bias.data for p in self._parts], 0)
 
 
 def _set_out(a, out, B, cout, Lout):

@@ -1,0 +1,121 @@
+"""Pre-LN transformer encoder of the Mega-TTS2 PLM (reference ttv_v1/transformer_mega.py).
+
+The reference works time-major ``[B, T, D]``; here a batch is ONE channel-major matrix
+``[1, D, B*T]`` with the utterances side by side on the column axis (``batch=(B, T)`` tells the
+attention where they are), so that every ``nn.Linear`` is a single GEMM over all B*T tokens on the
+MFMA conv kernel; the three q/k/v projections run as one stacked GEMM, attention is ``hsp_mha_f32``
+on strided views.  Inference only: dropout is the identity
+(transformer_mega.py:78 passes ``dropout_p = 0`` outside training)."""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import functional as Fh
+from ..hip_layers import HipLayer, LinearCT, StackedLinearCT
+
+
+class LayerNorm(HipLayer):
+    """torch.nn.LayerNorm(dim) (parameter names ``weight`` / ``bias``) over the channel axis of [B, D, T]."""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(dim), requires_grad=False)
+        self._g = self._b = None
+
+    def hsp_requests(self):
+        return [("g", self.dim), ("b", self.dim)]
+
+    def hsp_fill(self, arena, materialize):
+        self._g, self._b = arena.view(self, "g"), arena.view(self, "b")
+        if materialize:
+            self._g.copy_(self.weight.data)
+            self._b.copy_(self.bias.data)
+
+    def forward(self, x):
+        if self._g is None:
+            raise L.HspError("LayerNorm used before finalize()")
+        return Fh.layernorm_mod(x, self.eps, gamma=self._g, beta=self._b)
+
+
+class MultiHeadAttention(nn.Module):
+    """transformer_mega.MultiHeadAttention (:44-87), self-attention without a mask (the only form
+    Megatts2PLM1.infer uses: ``self.plm(x_pos)`` passes no lengths, t2w2v_transformer.py:715)."""
+
+    def __init__(self, qkv_dim, n_heads=8, dropout=0.):
+        super().__init__()
+        assert qkv_dim % n_heads == 0
+        self.n_heads, self.head_dim, self.qkv_dim = n_heads, qkv_dim // n_heads, qkv_dim
+        self.w_q = LinearCT(qkv_dim, qkv_dim, packed=False)
+        self.w_k = LinearCT(qkv_dim, qkv_dim, packed=False)
+        self.w_v = LinearCT(qkv_dim, qkv_dim, packed=False)
+        self.qkv = StackedLinearCT([self.w_q, self.w_k, self.w_v])
+        self.out_proj = nn.ModuleList([LinearCT(qkv_dim, qkv_dim)])  # nn.Sequential(Linear, Dropout): key "out_proj.0"
+
+    def forward(self, x, kv=None, mask=None, res=None, batch=None, last_only=False):
+        """x [1, D, B*T] -> out_proj(attention) [+ res]; ``last_only`` -> [1, D, B]: only the last
+        position of every utterance (columns T-1, 2T-1, ...), ``res`` then being [1, D, B] already."""
+        if kv is not None or mask is not None:
+            raise NotImplementedError("cross-attention / masks are not on the PLM inference path")
+        D = self.qkv_dim
+        B, T = batch if batch is not None else (x.shape[0], x.shape[2])
+        qkv = self.qkv(x)
+        o = torch.empty_like(x)
+        per_utt = lambda m: m.reshape(-1, B, T).permute(1, 0, 2) if batch is not None else m  # [B, C, T] view
+        q, k, v = (per_utt(qkv[0, i * D:(i + 1) * D]) if batch is not None else qkv[:, i * D:(i + 1) * D]
+                   for i in range(3))
+        Fh.mha(q, k, v, self.n_heads, 1.0 / math.sqrt(self.head_dim), out=per_utt(o[0]) if batch is not None else o)
+        if last_only:
+            o = o[0].reshape(D, B, T)[:, :, T - 1].unsqueeze(0)  # [1, D, B] view, time stride T
+        return self.out_proj[0](o, res=res)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """transformer_mega.TransformerEncoderLayer (:89-132), ``conv_ff=False``."""
+
+    def __init__(self, dim, ff_dim, conv_ff=False, n_heads=8, dropout=0.):
+        super().__init__()
+        if conv_ff:
+            raise NotImplementedError("Megatts2PLM1 builds its layers with conv_ff=False")
+        self.dim, self.ff_dim, self.conv_ff, self.n_heads = dim, ff_dim, conv_ff, n_heads
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.attn = MultiHeadAttention(dim, n_heads=n_heads, dropout=dropout)
+        # nn.Sequential(Linear, ReLU, Dropout, Linear): keys "ff.0" and "ff.3"
+        self.ff = nn.ModuleDict({"0": LinearCT(dim, ff_dim), "3": LinearCT(ff_dim, dim)})
+
+    def forward(self, x, mask=None, batch=None, last_only=False):
+        """``last_only`` returns just the last position of every utterance ``[1, D, B]`` (all the
+        greedy loop reads from the final layer); attention still sees the whole prefix."""
+        res = x
+        if last_only:
+            B, T = batch
+            res = Fh.copy_strided(x[0].reshape(-1, B, T)[:, :, T - 1].unsqueeze(0))
+        x = self.attn(self.norm1(x), mask=mask, res=res, batch=batch, last_only=last_only)
+        h = self.ff["0"](self.norm2(x), act=L.ACT_RELU)
+        return self.ff["3"](h, res=x)
+
+
+class TransformerEncoder(nn.Module):
+    """transformer_mega.TransformerEncoder (:135-163)."""
+
+    def __init__(self, encoder_layer: TransformerEncoderLayer, num_layers: int, norm=None):
+        super().__init__()
+        e = encoder_layer
+        self.layers = nn.ModuleList([e] + [TransformerEncoderLayer(e.dim, e.ff_dim, e.conv_ff, e.n_heads)
+                                           for _ in range(num_layers - 1)])
+        self.num_layers, self.norm = num_layers, norm
+
+    def forward(self, x, x_lens=None, causal=False, batch=None, last_only=False):
+        if x_lens is not None or causal:
+            raise NotImplementedError("length / causal masks belong to the training forward, not to infer()")
+        for i, layer in enumerate(self.layers):
+            x = layer(x, batch=batch, last_only=last_only and i == self.num_layers - 1)
+        if self.norm is not None:
+            x = self.norm(x)
+        return x

@@ -60,7 +60,8 @@ def run_oracle(meta, arrays):
     mask = None
     if "lengths" in arrays:
         T = {"dit_block": lambda: arrays["x"].shape[1], "style_encoder": lambda: arrays["mel"].shape[2],
-             "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2]}.get(
+             "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2],
+             "plm": lambda: arrays["tc"].shape[2]}.get(
             kind, lambda: arrays["x"].shape[2])()
         mask = O.sequence_mask(t("lengths"), T).unsqueeze(1).float()
     if kind == "act1d":
@@ -97,12 +98,15 @@ def run_oracle(meta, arrays):
     if kind == "vc":
         return [O.synth_voice_conversion_noise_control(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"),
                                                        t("f0"), meta["noise_scale"], meta["denoise_ratio"], t("noise"))]
-    if kind == "rel_mha":
-        from megatts2_hierspeechpp_amd import attentions
-        return attentions.MultiHeadAttention(256, 256, meta["heads"], window_size=meta["window"])
-    if kind == "vits_encoder":
-        from megatts2_hierspeechpp_amd import attentions
-        return attentions.Encoder(256, 1024, meta["heads"], meta["layers"], kernel_size=meta["k"], window_size=meta["window"])
+    if kind == "plm":
+        # per utterance, as the reference loop runs (B = 1); positions past a length are -1 / 0
+        tc, lens = t("tc"), arrays["lengths"]
+        codes = torch.full(tc.shape[::2], -1.0)
+        logits = torch.zeros(tc.shape[0], tc.shape[2], 1024)
+        for b, n in enumerate(lens):
+            c, lg = O.plm_infer(sd, name, tc[b:b + 1, :, :n], return_logits=True)
+            codes[b, :n], logits[b, :n] = c[0].float(), lg[0]
+        return [codes, logits]
     if kind == "speechsr":
         return [O.speechsr(sd, t("x"), meta["factor"], name + ".dec")]
     raise KeyError(kind)
@@ -154,6 +158,9 @@ def build_module(meta):
     if kind == "vits_encoder":
         from megatts2_hierspeechpp_amd import attentions
         return attentions.Encoder(256, 1024, meta["heads"], meta["layers"], kernel_size=meta["k"], window_size=meta["window"])
+    if kind == "plm":
+        from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import Megatts2PLM1
+        return Megatts2PLM1()
     if kind == "speechsr":
         from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SR
         return SR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [meta["factor"]], 32, [3])
@@ -172,7 +179,8 @@ def run_hip(meta, arrays, device):
     mask = None
     if "lengths" in arrays:
         T = {"dit_block": lambda: arrays["x"].shape[1], "style_encoder": lambda: arrays["mel"].shape[2],
-             "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2]}.get(
+             "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2],
+             "plm": lambda: arrays["tc"].shape[2]}.get(
             kind, lambda: arrays["x"].shape[2])()
         mask = Fh.sequence_mask(d("lengths"), T)
     with torch.no_grad():
@@ -184,6 +192,12 @@ def run_hip(meta, arrays, device):
             out = [mod(d("x"), d("x"), mask_q=mask, mask_k=mask)]
         elif kind == "vits_encoder":
             out = [mod(d("x"), mask)]
+        elif kind == "plm":
+            # one batched run; rows shorter than the longest are cut to the fixture's -1 / 0 padding
+            codes, logits = mod.infer(d("tc"), return_logits=True)
+            valid = mask[:, 0] > 0
+            out = [torch.where(valid, codes.float(), torch.full_like(valid, -1.0, dtype=torch.float32)),
+                   logits * valid.unsqueeze(-1)]
         elif kind == "dit_block":
             out = [mod(d("x").transpose(1, 2).contiguous(), d("c"), mask).transpose(1, 2)]
         elif kind == "coupling":

@@ -122,21 +122,83 @@ def rnd(seed, *shape, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
 
 
+# ------------------------------------------------------------------- ttv_v1 (front-end, PLM)
+def install_ttv_stubs():
+    """Third-party modules ttv_v1/t2w2v_transformer.py imports at module level but never touches on
+    the inference path: monotonic_align (training-time alignment, a Cython build product that is not
+    in the checkout) and torchmetrics (a training accuracy metric built in Megatts2PLM1.__init__)."""
+    def fake(name):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        sys.modules[name] = m
+        return m
+
+    ma, mc = fake("monotonic_align"), fake("monotonic_align.core")
+    ma.core, mc.maximum_path_c, ma.mask_from_lens, ma.maximum_path = mc, None, None, None
+    fake("torchmetrics")
+    tmc = fake("torchmetrics.classification")
+
+    class MulticlassAccuracy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    tmc.MulticlassAccuracy = MulticlassAccuracy
+
+
+def ttv_cases():
+    install_ttv_stubs()
+    import logging
+    logging.getLogger("matplotlib").setLevel(logging.WARNING)
+    from ttv_v1 import t2w2v_transformer as TT
+    W = 7
+
+    # -- A18: Megatts2PLM1.infer; the logits of each step's last position are captured with a forward
+    #         hook on predict_layer.  B > 1 fixtures are the reference run once per utterance (its
+    #         loop is B = 1 only), with ragged lengths.
+    name = "plm"
+    mod = TT.Megatts2PLM1()
+    shapes, sd = load_synth(mod, W, name + ".")
+    captured = []
+    mod.predict_layer.register_forward_hook(lambda m, i, o: captured.append(o[:, -1].clone()))
+    for case, lens in [("plm_t12", [12]), ("plm_b3_t40", [40, 23, 31])]:
+        Tm = max(lens)
+        tc = rnd(300 + Tm, len(lens), 256, Tm)
+        codes = np.full((len(lens), Tm), -1, np.int64)
+        logits = np.zeros((len(lens), Tm, 1024), np.float32)
+        ocodes, ologits = np.full_like(codes, -1), np.zeros_like(logits)
+        for b, n in enumerate(lens):
+            captured.clear()
+            codes[b, :n] = mod.infer(t(tc[b:b + 1, :, :n]))[0].numpy()
+            logits[b, :n] = torch.cat(captured, 0).numpy()
+            oc, ol = O.plm_infer(sd, name, t(tc[b:b + 1, :, :n]), return_logits=True)
+            ocodes[b, :n], ologits[b, :n] = oc[0].numpy(), ol[0].numpy()
+        assert (codes == ocodes).all(), f"{case}: oracle codes differ from the reference"
+        save(case, dict(kind="plm", prefix=name, seed=W, shapes=shapes), dict(tc=tc, lengths=np.array(lens, np.int64)),
+             [t(codes.astype(np.float32)), t(logits)], [t(ocodes.astype(np.float32)), t(ologits)])
+
+
 # ----------------------------------------------------------------------------- cases
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv"],
+                    help="vocoder: hierspeechpp/attentions/speechsr cases; ttv: ttv_v1 front-end + PLM cases")
     args = ap.parse_args()
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
     install_stubs()
     sys.path.insert(0, args.ref)
+    os.makedirs(OUT, exist_ok=True)
+    if args.group in ("all", "ttv"):
+        with torch.no_grad():
+            ttv_cases()
+    if args.group == "ttv":
+        return
     import hierspeechpp_speechsynthesizer as H
     import modules as M
     import activations
     from alias_free_torch import Activation1d
     from styleencoder import StyleEncoder
-    os.makedirs(OUT, exist_ok=True)
     cfg = O.default_config()
     W = 7  # weight seed
 
