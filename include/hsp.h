@@ -231,6 +231,39 @@ int hsp_argmax_f32(const float* logits, int64_t l_bs, int64_t l_cs, int32_t B, i
 int hsp_copy_strided_f32(const float* x, int64_t s_bs, int64_t s_cs, int64_t s_ts, float* y, int32_t B,
                          int32_t C, int32_t T, void* stream);
 
+
+/* ---------------------------------------------- t2w2v front-end */
+/* out[b, c, t] = sum_k tab_k[id_k[b, t], c] * scale over up to three tables (tab1 / tab2 may be
+ * NULL), channel-major output with strides (o_bs, o_cs, 1) : TextEncoder.forward
+ * (ttv_v1/t2w2v_transformer.py:127-131); one table with scale 1 = the RVQ codebook lookup of
+ * quantizer.decode (ttv_v1/core_vq.py:188-190,380-386). */
+int hsp_embedding_sum_f32(const int64_t* id0, const int64_t* id1, const int64_t* id2, const float* tab0,
+                          const float* tab1, const float* tab2, int32_t n0, int32_t n1, int32_t n2, float scale,
+                          float* out, int64_t o_bs, int64_t o_cs, int32_t B, int32_t C, int32_t T, void* stream);
+/* One bidirectional torch.nn.LSTM layer (gate order i, f, g, o; zero initial state), the recurrence
+ * only: xproj[b][dir][4H][N] = x W_ih^T + b_ih (a 1x1 GEMM), whh_t[dir][H][4H] = W_hh^T,
+ * bhh[dir][4H]; utterance b runs lengths[b] steps (the reverse direction from its own last step, as a
+ * packed sequence does) and writes zeros after; out[b, dir*H + j, t] with strides (o_bs, o_cs, 1).
+ * nn.LSTM of DurationPredictor (ttv_v1/vits_models.py:101,125) and RangePredictor (ttv_v1/Gaussian.py:100-110). */
+int hsp_lstm_bidir_f32(const float* xproj, int64_t xp_bs, const float* whh_t, const float* bhh,
+                       const int64_t* lengths, float* out, int64_t o_bs, int64_t o_cs, int32_t B, int32_t H,
+                       int32_t N, void* stream);
+/* dur[b, n] = n < lengths[b] ? ceil(exp(logw[b, n]) * length_scale) : 0, frames[b] = sum_n dur[b, n]
+ * (ttv_v1/t2w2v_transformer.py:955-957,972-975).  logw == NULL keeps caller-supplied durations and only
+ * zeroes the padding / sums. */
+int hsp_duration_f32(const float* logw, int64_t lw_bs, const int64_t* lengths, float length_scale, float* dur,
+                     int64_t d_bs, float* frames, int32_t B, int32_t N, void* stream);
+/* GaussianUpsampling.forward (ttv_v1/Gaussian.py:35-69) with the range clamp
+ * min(range, 2 dur), max(., 1e-5) of ttv_v1/t2w2v_transformer.py:961-963: x [B, C, N] (strides x_bs, x_cs, 1)
+ * -> out [B, C, T] contiguous, frames t >= frames[b] zero. */
+int hsp_gaussian_upsample_f32(const float* x, int64_t x_bs, int64_t x_cs, const float* dur, int64_t d_bs,
+                              const float* rng, int64_t r_bs, const int64_t* lengths, const float* frames,
+                              float* out, int32_t B, int32_t C, int32_t N, int32_t T, void* stream);
+/* y[b, c, t] (contiguous) = x[b, c, t] + cb[b, c] : `x + self.cond(g)` with a per-utterance vector
+ * (ttv_v1/vits_models.py:119, ttv_v1/t2w2v_transformer.py:222) */
+int hsp_add_cbias_f32(const float* x, int64_t x_bs, int64_t x_cs, const float* cb, int64_t cb_bs, float* y,
+                      int32_t B, int32_t C, int32_t T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

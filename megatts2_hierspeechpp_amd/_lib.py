@@ -81,6 +81,14 @@ SIGNATURES = {
     "hsp_plm_embed_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int32, C.c_int32,
                                     _fp, C.c_int32, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp]),
     "hsp_argmax_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64, _fp]),
+    "hsp_embedding_sum_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp,
+                                        C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_lstm_bidir_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                     C.c_int32, _fp]),
+    "hsp_duration_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_float, _fp, C.c_int64, _fp, C.c_int32, C.c_int32, _fp]),
+    "hsp_gaussian_upsample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp,
+                                            C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_add_cbias_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_copy_strided_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32,
                                        _fp]),
 }

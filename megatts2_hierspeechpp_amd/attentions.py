@@ -95,7 +95,7 @@ class MultiHeadAttention(HipLayer):
             self._rk.copy_(self.emb_rel_k.data.reshape(-1))
             self._rv.copy_(self.emb_rel_v.data.reshape(-1))
 
-    def forward(self, x, c, attn_mask=None, *, mask_q=None, mask_k=None, res=None):
+    def forward(self, x, c, attn_mask=None, *, mask_q=None, mask_k=None, res=None, cbias=None, out=None):
         """``attn_mask`` of the reference is always mask_k[b, j] * mask_q[b, i]
         (attentions.py:39, styleencoder.py:71); pass the two [B, 1, T] factors."""
         if attn_mask is not None:
@@ -105,4 +105,4 @@ class MultiHeadAttention(HipLayer):
         rel_v = self._rv if self.window_size is not None else None
         o = Fh.mha(q, k, v, self.n_heads, 1.0 / math.sqrt(self.k_channels), mask_q=mask_q, mask_k=mask_k,
                    rel_k=rel_k, rel_v=rel_v, window=self.window_size or 0)
-        return self.conv_o(o, res=res)
+        return self.conv_o(o, res=res, cbias=cbias, out=out)

@@ -282,12 +282,12 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
   }
 }
 
-// Register-resident variant for C <= 16 * LN_R: a workgroup owns 16 time columns, its 256 threads
+// Register-resident variant for C <= 16 * LN_R = 512: a workgroup owns 16 time columns, its 256 threads
 // are 16 columns x 16 channel groups and every thread keeps its <= LN_R channel values in
 // registers, so the tile is read once with all loads in flight (the loop kernel above chases
 // C/4 dependent loads three times: ~40 us for C = 276 whatever T is).  Short sequences still
 // give B * T/16 workgroups.
-constexpr int LN_R = 24;
+constexpr int LN_R = 32;
 __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
                                                             int T, float eps, const float* __restrict__ mask,
                                                             const float* __restrict__ shift,

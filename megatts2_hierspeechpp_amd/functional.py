@@ -139,3 +139,29 @@ def copy_strided(x):
     L.check(L.lib().hsp_copy_strided_f32(L.fptr(x), x.stride(0), x.stride(1), x.stride(2), L.fptr(y), B, Cc, T,
                                          L.stream_ptr()), "hsp_copy_strided_f32")
     return y
+
+
+def add_cbias(x, cb):
+    """x [B, C, T] (strided ok) + cb [B, C(, 1)] broadcast over T -> contiguous [B, C, T]."""
+    B, Cc, T = x.shape
+    assert x.stride(2) == 1 and cb.stride(1) == 1 and cb.shape[:2] == (B, Cc)
+    y = torch.empty(B, Cc, T, dtype=torch.float32, device=x.device)
+    L.check(L.lib().hsp_add_cbias_f32(L.fptr(x), x.stride(0), x.stride(1), L.fptr(cb), cb.stride(0), L.fptr(y), B, Cc, T,
+                                      L.stream_ptr()), "hsp_add_cbias_f32")
+    return y
+
+
+def embedding_sum(ids, tables, n_rows, scale: float, channels: int, out=None):
+    """Channel-major sum of up to three embedding lookups: ids = list of int64 [B, T], tables = list of
+    flat fp32 tables [rows * channels] -> [B, channels, T]."""
+    B, T = ids[0].shape
+    if out is None:
+        out = torch.empty(B, channels, T, dtype=torch.float32, device=ids[0].device)
+    ids = [_c(i.to(torch.int64)) for i in ids] + [None] * (3 - len(ids))
+    tables = list(tables) + [None] * (3 - len(tables))
+    n_rows = list(n_rows) + [0] * (3 - len(n_rows))
+    L.check(L.lib().hsp_embedding_sum_f32(L.ptr(ids[0]), L.ptr(ids[1]), L.ptr(ids[2]), L.fptr(tables[0]),
+                                          L.fptr(tables[1]), L.fptr(tables[2]), n_rows[0], n_rows[1], n_rows[2],
+                                          float(scale), L.fptr(out), out.stride(0), out.stride(1), B, channels, T,
+                                          L.stream_ptr()), "hsp_embedding_sum_f32")
+    return out

@@ -281,7 +281,7 @@ class ConvTranspose1d(_ConvBase):
             if self._b is not None:
                 self._b.copy_(self.bias.data)
 
-    def forward(self, x, *, res=None, out=None):
+    def forward(self, x, *, res=None, out=None, lrelu: Optional[float] = None):
         self._require_ready()
         B, Cin, Lin = x.shape
         assert Cin == self.cin
@@ -299,6 +299,8 @@ class ConvTranspose1d(_ConvBase):
         a.rows, a.up, a.shuf_pad = L.ROWS_SHUFFLE, self.up, self.padding
         a.bias = L.fptr(self._b)
         _set_epilogue(a, L.ACT_NONE, None, None, L.MASK_NONE, None, 1.0, res, False, 1.0, out)
+        if lrelu is not None:
+            a.prologue, a.slope = L.PRO_LRELU, float(lrelu)
         flops = 2 * B * Cin * self.cout * self.k * Lin
         nbytes = 4 * (B * Cin * Lin + B * self.cout * Lout * (1 + (res is not None)) + Cin * self.cout * self.k)
         _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)

@@ -35,13 +35,19 @@ class StyleEncoder(nn.Module):
                                                       proximal_bias=False, proximal_init=True)
         self.fc = Conv1d(hidden_dim, out_dim, 1)
 
-    def forward(self, x, mask=None):
-        """styleencoder.py:63-81: x [B, in_dim, T], mask [B, 1, T] -> [B, out_dim]."""
+    def forward(self, x, mask=None, per_utterance=False):
+        """styleencoder.py:63-81: x [B, in_dim, T], mask [B, 1, T] -> [B, out_dim].
+
+        The reference does not mask between its two Conv1dGLU layers and its average pool sums the
+        padded frames too, so in a ragged batch the padding of a short row leaks into its style vector;
+        that is reproduced by default (the vocoder path takes batches).  ``per_utterance=True`` masks there too, making every row equal to the B = 1 result on
+        that utterance alone -- the semantics of the B = 1-only text front-end."""
         assert mask is not None
         x = self.spectral[0](x, act=L.ACT_MISH)
         x = self.spectral[3](x, act=L.ACT_MISH, mask=mask, mask_mode=L.MASK_PRE)
-        x = self.temporal[0](x)
+        x = self.temporal[0](x, mask=mask if per_utterance else None)
         x = self.temporal[1](x, mask=mask)
         x = self.slf_attn(x, x, mask_q=mask, mask_k=mask, res=x)
-        x = self.fc(x)
+        # temporal_avg_pool (:83-91) sums over ALL frames, padding included, and divides by the length
+        x = self.fc(x, **(dict(mask=mask, mask_mode=L.MASK_POST) if per_utterance else {}))
         return Fh.masked_mean(x, mask)

@@ -9,6 +9,7 @@ multi-GPU run) can regenerate any tensor independently of iteration order.
 * plain conv / linear weights ``N(0,1)/sqrt(fan_in)`` (this also re-randomises the layers
   the reference zero-initialises -- ``post`` and ``adaLN_modulation`` -- without which
   the flow parity would be vacuous)
+* nn.LSTM matrices ``N(0,1)/sqrt(fan_in)``, nn.LayerNorm gains ``1 + 0.1·N``
 * resample filters: the closed-form 12-tap kaiser-sinc
 """
 from __future__ import annotations
@@ -58,6 +59,12 @@ def synth_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
         return 0.1 * n()
     if leaf in ("emb_rel_k", "emb_rel_v"):
         return n() * (shape[-1] ** -0.5)
+    if leaf.startswith(("weight_ih", "weight_hh")):   # nn.LSTM
+        return n() / math.sqrt(shape[1])
+    if leaf.startswith(("bias_ih", "bias_hh")):
+        return 0.1 * n()
+    if leaf == "weight" and len(shape) == 1:           # nn.LayerNorm gain
+        return 1.0 + 0.1 * n()
     if leaf == "weight":
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
         return n() / math.sqrt(max(fan_in, 1))

@@ -7,8 +7,16 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from ..hip_layers import HipLayer, LinearCT, finalize as _finalize
+from .. import attentions
+from .. import functional as Fh
+from ..hip_layers import Conv1d, ConvTranspose1d, HipLayer, LinearCT, finalize as _finalize
+from ..styleencoder import StyleEncoder
+from . import modules
+from .Gaussian import GaussianUpsampling, RangePredictor
+from .modules import WN
+from .quantize import ResidualVectorQuantizer
 from .transformer_mega import TransformerEncoder, TransformerEncoderLayer
+from .vits_models import DurationPredictor
 
 
 class SinePositionalEmbedding(HipLayer):
@@ -127,3 +135,218 @@ class Megatts2PLM1(nn.Module):
             L.check(L.lib().hsp_argmax_f32(L.fptr(lg), 1, B, B, self.vq_bins, L.ptr(codes[:, t + 1:]),
                                            codes.stride(0), L.stream_ptr()), "hsp_argmax_f32")
         return (codes[:, 1:], all_logits.permute(2, 0, 1)) if return_logits else codes[:, 1:]
+
+
+# ======================================================================= front-end
+class TextEncoder(nn.Module):
+    """t2w2v_transformer.TextEncoder (:82-143).  ``cond`` / ``proj`` of the reference are dead code on
+    every path (their uses are commented out) and are not mirrored."""
+
+    def __init__(self, n_vocab, n_tone, n_language, out_channels, hidden_channels, filter_channels, n_heads, n_layers,
+                 kernel_size, p_dropout):
+        super().__init__()
+        self.n_vocab, self.n_tone, self.n_language, self.hidden_channels = n_vocab, n_tone, n_language, hidden_channels
+        self.emb = Embedding(n_vocab, hidden_channels)
+        self.emb_tone = Embedding(n_tone, hidden_channels)
+        self.emb_language = Embedding(n_language, hidden_channels)
+        self.encoder = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.encoder2 = attentions.Encoder(hidden_channels, filter_channels, n_heads, 1, kernel_size, p_dropout)
+
+    def forward(self, x, x_lengths, g, tone, language, out=None):
+        h = Fh.embedding_sum([x, tone, language], [self.emb._w, self.emb_tone._w, self.emb_language._w],
+                             [self.n_vocab, self.n_tone, self.n_language], math.sqrt(self.hidden_channels),
+                             self.hidden_channels)
+        x_mask = Fh.sequence_mask(x_lengths, h.shape[2])
+        h = self.encoder(h, x_mask)
+        h = self.encoder2(h, x_mask)
+        return h, x_mask
+
+
+class MelEncoder(nn.Module):
+    """t2w2v_transformer.MelEncoder (:145-179)."""
+
+    def __init__(self, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout):
+        super().__init__()
+        self.encoder = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.proj = Conv1d(hidden_channels, out_channels, 1)
+
+    def forward(self, x, x_lengths):
+        x_mask = Fh.sequence_mask(x_lengths, x.shape[2])
+        return self.proj(self.encoder(x, x_mask), mask=x_mask, mask_mode=L.MASK_POST), x_mask
+
+
+class W2VEncoder(nn.Module):
+    """t2w2v_transformer.W2VEncoder (:182-226); ``project`` / ``proj`` are dead code there."""
+
+    def __init__(self, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout):
+        super().__init__()
+        self.cond = Conv1d(256, hidden_channels, 1)
+        self.encoder = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.encoder2 = attentions.Encoder(hidden_channels, filter_channels, n_heads, 1, kernel_size, p_dropout)
+
+    def forward(self, x, x_lengths, g, x_mask=None, cond_added=False):
+        """``cond_added``: the caller already fused ``+ cond(g)`` into the conv that produced x."""
+        if x_mask is None:
+            x_mask = Fh.sequence_mask(x_lengths, x.shape[2])
+        if not cond_added:
+            x = Fh.add_cbias(x, self.cond(g, force_direct=True))
+        return self.encoder2(self.encoder(x, x_mask), x_mask), x_mask
+
+
+class W2VDecoder(nn.Module):
+    """t2w2v_transformer.W2VDecoder (:377-405)."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, output_size=1024,
+                 gin_channels=0, p_dropout=0):
+        super().__init__()
+        self.pre = Conv1d(in_channels, hidden_channels, 1)
+        self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels, p_dropout=p_dropout)
+        self.proj = Conv1d(hidden_channels, output_size, 1)
+
+    def forward(self, x, x_mask, g=None):
+        # pre(x * mask) * mask: x arrives masked from the encoder
+        x = self.pre(x, mask=x_mask, mask_mode=L.MASK_POST)
+        x = self.enc(x, x_mask, g=g)
+        return self.proj(x, mask=x_mask, mask_mode=L.MASK_POST)
+
+
+class PitchPredictor(nn.Module):
+    """t2w2v_transformer.PitchPredictor (:408-463): HiFi-GAN style x4 upsampler, w2v -> log-f0."""
+
+    def __init__(self):
+        super().__init__()
+        ks, ups, ch0 = [3, 5, 7], [(2, 4), (2, 4)], 256
+        self.num_kernels, self.num_upsamples = len(ks), len(ups)
+        self.conv_pre = Conv1d(1024, ch0, 7, padding=3)
+        self.ups = nn.ModuleList([ConvTranspose1d(ch0 // 2 ** i, ch0 // 2 ** (i + 1), k, u, padding=(k - u) // 2,
+                                                  weight_norm=True) for i, (u, k) in enumerate(ups)])
+        self.resblocks = nn.ModuleList([modules.ResBlock1(ch0 // 2 ** (i + 1), k, (1, 3, 5))
+                                        for i in range(len(ups)) for k in ks])
+        self.conv_post = Conv1d(ch0 // 2 ** len(ups), 1, 7, padding=3, bias=False)
+        self.cond = Conv1d(256, ch0, 1)
+
+    def forward(self, x, g, lengths=None):
+        """``lengths`` (int64 [B], 50 Hz frames): zero every intermediate past an utterance's end, so a
+        short row of a batch sees the same zero padding as when it runs alone (the reference has no mask
+        here and runs B = 1)."""
+        B, _, T = x.shape
+        mk = (lambda r: Fh.sequence_mask(lengths * r, T * r)) if lengths is not None else (lambda r: None)
+        mm = lambda m: dict(mask=m, mask_mode=L.MASK_POST) if m is not None else {}
+        x = self.conv_pre(x, cbias=self.cond(g, force_direct=True), **mm(mk(1)))
+        for i in range(self.num_upsamples):
+            m = mk(2 ** (i + 1))
+            x = self.ups[i](x, lrelu=modules.LRELU_SLOPE)
+            if m is not None:
+                x = Fh.mask_mul(x, m)
+            xs = torch.empty_like(x)
+            for j in range(self.num_kernels):
+                self.resblocks[i * self.num_kernels + j](x, x_mask=m, out=xs, accumulate=j > 0,
+                                                         post_scale=1.0 / self.num_kernels if j == self.num_kernels - 1 else 1.0)
+            x = xs
+        return self.conv_post(x, lrelu=0.01)   # F.leaky_relu default slope (:458)
+
+
+class SynthesizerTrn(nn.Module):
+    """t2w2v_transformer.SynthesizerTrn (:721-994), inference members only
+    (``inf_extract_tc_latent``, ``inf_plm_gen``).  Same constructor signature; sub-modules that only the
+    training ``forward`` touches (``lr``, ``plm_conv1/2``, ``vq_pooling``) are not built, so reference
+    checkpoints load with ``strict=False``.
+
+    The reference front-end is B = 1 only (RangePredictor's ``.squeeze()`` and the [B,1,N] x [B,N]
+    broadcast at :961 break for B > 1).  Here a batch is B independent utterances: every stage honours
+    the per-utterance lengths so that row b equals the reference run on utterance b alone, and frames
+    past an utterance's length are zero."""
+
+    def __init__(self, n_vocab, n_tone, n_language, spec_channels, hop_length, sampling_rate, segment_size,
+                 inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
+                 resblock_kernel_sizes, resblock_dilation_sizes, gin_channels=256, prosody_size=20, cfg=False,
+                 freeze_quantizer=None, **kwargs):
+        super().__init__()
+        self.inter_channels, self.hidden_channels, self.stride = inter_channels, hidden_channels, 8
+        ic = inter_channels
+        self.enc_p = TextEncoder(n_vocab, n_tone, n_language, out_channels=ic, hidden_channels=ic, filter_channels=ic * 4,
+                                 n_heads=4, n_layers=3, kernel_size=9, p_dropout=0.2)
+        self.mel_encoder = MelEncoder(out_channels=256, hidden_channels=80, filter_channels=80 * 4, n_heads=4, n_layers=2,
+                                      kernel_size=9, p_dropout=0.2)
+        self.mha = attentions.MultiHeadAttention(ic, ic, n_heads=4, p_dropout=0.2)
+        self.cond_g = Conv1d(256, ic, 1)
+        self.w2v_encoder = W2VEncoder(out_channels=ic, hidden_channels=ic, filter_channels=ic * 4, n_heads=4, n_layers=3,
+                                      kernel_size=9, p_dropout=0.2)
+        self.w2v_decoder = W2VDecoder(ic, ic * 2, 5, 1, 8, output_size=1024, p_dropout=0.1, gin_channels=256)
+        self.emb_g = StyleEncoder(in_dim=80, hidden_dim=256, out_dim=256)
+        self.duration_predictor = DurationPredictor(hidden_channels, 256, 3, 0.5, gin_channels=gin_channels)
+        self.RangePredictor = RangePredictor(257, 256)
+        self.gaussian = GaussianUpsampling()
+        self.dur_downsample = Conv1d(hidden_channels, hidden_channels, 1)   # stride 2: run on an x[..., ::2] view
+        self.pp = PitchPredictor()
+        self.quantizer = ResidualVectorQuantizer(dimension=20, n_q=1, bins=1024)
+        self.ssl_proj = Conv1d(20, ic, 1)
+
+    # keys of the reference checkpoint that no inference path reads
+    UNUSED = ("lr.", "plm_conv1.", "plm_conv2.", "enc_p.cond.", "enc_p.proj.", "w2v_encoder.project.", "w2v_encoder.proj.")
+    UNUSED_LEAVES = ("_codebook.inited", "_codebook.cluster_size", "_codebook.embed_avg")
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts the reference's checkpoints: a bare state dict or utils.load_checkpoint's {'model': ...}
+        (inference_plm.py:233); training-only / dead keys are skipped."""
+        if "model" in state_dict and not any(k.startswith("enc_p.") for k in state_dict):
+            state_dict = state_dict["model"]
+        sd = {k: v for k, v in state_dict.items() if not k.startswith(self.UNUSED) and not k.endswith(self.UNUSED_LEAVES)}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def finalize(self, device, materialize: bool = True):
+        self.arena = _finalize(self, device, materialize)
+        return self
+
+    @torch.no_grad()
+    def inf_extract_tc_latent(self, x, x_lengths, y_mel, y_length, tone, language, mrte_mel=None, mrte_mel_lengths=None,
+                              length_scale=1, dur=None):
+        """(:937-982) ids/tone/language int64 [B, N], x_lengths [B], y_mel [B, 80, Tm], y_length [B] ->
+        x_frame [B, 256, T2], g [B, 256, 1], x_lengths (float, frames / 2) [B], x_mask fp32 [B, 1, T2].
+        ``dur`` [B, N] (optional) overrides the predicted durations (BASELINE config 3 pins them)."""
+        B, N = x.shape
+        C = self.inter_channels
+        x_lengths = x_lengths.to(torch.int64)
+        ref_mel, ref_len = (mrte_mel, mrte_mel_lengths) if mrte_mel is not None else (y_mel, y_length)
+        g = self.emb_g(ref_mel, Fh.sequence_mask(ref_len, ref_mel.shape[2]), per_utterance=True).unsqueeze(-1)
+        h, x_mask = self.enc_p(x, x_lengths, g, tone, language)
+        mel_out, h_mask = self.mel_encoder(ref_mel, ref_len)
+        # x = x + mha(x, mel) + cond_g(g), written into the first 256 channels of the RangePredictor input
+        xd = torch.empty(B, C + 1, N, dtype=torch.float32, device=x.device)
+        xs = xd[:, :C]
+        self.mha(h, mel_out, mask_q=x_mask, mask_k=h_mask, res=h, cbias=self.cond_g(g, force_direct=True), out=xs)
+        frames = torch.empty(B, dtype=torch.float32, device=x.device)
+        dcol = xd[:, C]
+        if dur is None:
+            logw = self.duration_predictor(xs, x_mask, g=g, lengths=x_lengths)
+            lw = (L.fptr(logw), logw.stride(0))
+        else:
+            dcol.copy_(dur.to(torch.float32))
+            lw = (None, 0)
+        L.check(L.lib().hsp_duration_f32(lw[0], lw[1], L.ptr(x_lengths), float(length_scale), L.fptr(dcol), dcol.stride(0),
+                                         L.fptr(frames), B, N, L.stream_ptr()), "hsp_duration_f32")
+        rng = self.RangePredictor(xd, x_lengths)
+        frames_h = frames.cpu()                       # the reference's `.item()` (Gaussian.py:53): T is data dependent
+        T = int(frames_h.max().item())
+        x_frame = self.gaussian(xs, dcol, rng, x_lengths, frames, T)
+        frame_lengths = frames_h / 2                   # (:976) float, may end in .5
+        T2 = (T - 1) // 2 + 1
+        len2 = torch.ceil(frame_lengths).to(torch.int64).to(x.device)
+        mask2 = Fh.sequence_mask(len2, T2)
+        x_frame = self.dur_downsample(x_frame[:, :, ::2], mask=mask2, mask_mode=L.MASK_POST)
+        return x_frame, g, frame_lengths.to(x.device), mask2
+
+    @torch.no_grad()
+    def inf_plm_gen(self, x_frame, g, codes, x_lengths, x_mask):
+        """(:984-994) codes int64 [B, T2] (or the reference's [1, 1, T2]) -> w2v [B, 1024, T2], lf0 [B, 4 T2]."""
+        T2 = x_frame.shape[2]
+        q = self.quantizer.decode(codes)
+        # x_frame + ssl_proj(quantized) [+ w2v_encoder.cond(g), fused]
+        x = self.ssl_proj(q, res=x_frame, cbias=self.w2v_encoder.cond(g, force_direct=True))
+        len2 = torch.ceil(x_lengths.to(torch.float32)).to(torch.int64)
+        mask = Fh.sequence_mask(len2, T2)
+        x2v_enc, _ = self.w2v_encoder(x, x_lengths, g, x_mask=mask, cond_added=True)
+        w2v_pred = self.w2v_decoder(x2v_enc, mask, g=g)
+        lf0 = self.pp(w2v_pred, g, lengths=len2)
+        mask4 = Fh.sequence_mask(4 * len2, 4 * T2)
+        return w2v_pred, Fh.mask_mul(lf0, mask4).squeeze(1)

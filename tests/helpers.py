@@ -19,6 +19,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ATOL = 1e-4
 
 
+# ttv_v1/config.json "model" section of the reference (hyper-parameters, not code)
+TTV_MODEL = dict(inter_channels=256, hidden_channels=256, filter_channels=1024, n_heads=4, n_layers=6, kernel_size=3,
+                 p_dropout=0.1, resblock="1", resblock_kernel_sizes=[3, 7, 11],
+                 resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], use_spectral_norm=False)
+
+
 def fixture_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
 
@@ -61,7 +67,8 @@ def run_oracle(meta, arrays):
     if "lengths" in arrays:
         T = {"dit_block": lambda: arrays["x"].shape[1], "style_encoder": lambda: arrays["mel"].shape[2],
              "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2],
-             "plm": lambda: arrays["tc"].shape[2]}.get(
+             "plm": lambda: arrays["tc"].shape[2], "ttv_front": lambda: arrays["ids"].shape[1],
+             "ttv_gen": lambda: arrays["x_frame"].shape[2]}.get(
             kind, lambda: arrays["x"].shape[2])()
         mask = O.sequence_mask(t("lengths"), T).unsqueeze(1).float()
     if kind == "act1d":
@@ -98,6 +105,22 @@ def run_oracle(meta, arrays):
     if kind == "vc":
         return [O.synth_voice_conversion_noise_control(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"),
                                                        t("f0"), meta["noise_scale"], meta["denoise_ratio"], t("noise"))]
+    if kind == "ttv_front":
+        per = []
+        for b, (n, tm) in enumerate(zip(arrays["lengths"], arrays["mel_lengths"])):
+            xf, g, fl, _ = O.ttv_extract_tc_latent_one(sd, t("ids")[b:b + 1, :n], t("mel")[b:b + 1, :, :tm],
+                                                        t("tone")[b:b + 1, :n], t("language")[b:b + 1, :n])
+            per.append((xf, g, torch.tensor([fl])))
+        T2 = max(p[0].shape[2] for p in per)
+        return [torch.cat([torch.nn.functional.pad(p[0], (0, T2 - p[0].shape[2])) for p in per]),
+                torch.cat([p[1] for p in per]), torch.cat([p[2] for p in per])]
+    if kind == "ttv_gen":
+        xf, fl = t("x_frame"), arrays["frame_lengths"]
+        w2v, lf0 = torch.zeros(xf.shape[0], 1024, xf.shape[2]), torch.zeros(xf.shape[0], 4 * xf.shape[2])
+        for b, n in enumerate(arrays["lengths"]):
+            w, l0 = O.ttv_plm_gen_one(sd, xf[b:b + 1, :, :n], t("g")[b:b + 1], t("codes")[b:b + 1, :n], float(fl[b]))
+            w2v[b, :, :n], lf0[b, :4 * n] = w[0], l0[0]
+        return [w2v, lf0]
     if kind == "plm":
         # per utterance, as the reference loop runs (B = 1); positions past a length are -1 / 0
         tc, lens = t("tc"), arrays["lengths"]
@@ -161,6 +184,9 @@ def build_module(meta):
     if kind == "plm":
         from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import Megatts2PLM1
         return Megatts2PLM1()
+    if kind in ("ttv_front", "ttv_gen"):
+        from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import SynthesizerTrn as Text2W2V
+        return Text2W2V(126, 11, 4, 641, 320, 16000, 60, **TTV_MODEL)
     if kind == "speechsr":
         from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SR
         return SR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [meta["factor"]], 32, [3])
@@ -180,7 +206,8 @@ def run_hip(meta, arrays, device):
     if "lengths" in arrays:
         T = {"dit_block": lambda: arrays["x"].shape[1], "style_encoder": lambda: arrays["mel"].shape[2],
              "posterior_sf": lambda: arrays["w2v"].shape[2], "infer": lambda: arrays["mel"].shape[2],
-             "plm": lambda: arrays["tc"].shape[2]}.get(
+             "plm": lambda: arrays["tc"].shape[2], "ttv_front": lambda: arrays["ids"].shape[1],
+             "ttv_gen": lambda: arrays["x_frame"].shape[2]}.get(
             kind, lambda: arrays["x"].shape[2])()
         mask = Fh.sequence_mask(d("lengths"), T)
     with torch.no_grad():
@@ -192,6 +219,12 @@ def run_hip(meta, arrays, device):
             out = [mod(d("x"), d("x"), mask_q=mask, mask_k=mask)]
         elif kind == "vits_encoder":
             out = [mod(d("x"), mask)]
+        elif kind == "ttv_front":
+            xf, g, fl, _ = mod.inf_extract_tc_latent(d("ids"), d("lengths"), d("mel"), d("mel_lengths"), d("tone"),
+                                                     d("language"))
+            out = [xf, g, fl]
+        elif kind == "ttv_gen":
+            out = list(mod.inf_plm_gen(d("x_frame"), d("g"), d("codes"), d("frame_lengths"), None))
         elif kind == "plm":
             # one batched run; rows shorter than the longest are cut to the fixture's -1 / 0 padding
             codes, logits = mod.infer(d("tc"), return_logits=True)

@@ -27,6 +27,7 @@ import warnings
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -175,6 +176,67 @@ def ttv_cases():
         assert (codes == ocodes).all(), f"{case}: oracle codes differ from the reference"
         save(case, dict(kind="plm", prefix=name, seed=W, shapes=shapes), dict(tc=tc, lengths=np.array(lens, np.int64)),
              [t(codes.astype(np.float32)), t(logits)], [t(ocodes.astype(np.float32)), t(ologits)])
+
+    # -- A17: t2w2v SynthesizerTrn.inf_extract_tc_latent / inf_plm_gen.  The reference front-end is
+    #         B = 1 only (RangePredictor's .squeeze() and the [B,1,N] x [B,N] broadcast at :961 break for
+    #         B > 1), so ragged-batch fixtures are per-utterance reference runs, zero-padded.
+    import utils as ref_utils
+    hps = ref_utils.get_hparams_from_file(os.path.join(os.path.dirname(TT.__file__), "config.json"))
+    net = TT.SynthesizerTrn(126, 11, 4, 641, 320, 16000, 60, **hps.model)   # text/symbols_lmdh.py sizes
+    shapes, sd = load_synth(net, W, "")
+    front = ("emb_g", "enc_p", "mel_encoder", "mha", "cond_g", "duration_predictor", "RangePredictor", "dur_downsample")
+    gen = ("quantizer", "ssl_proj", "w2v_encoder", "w2v_decoder", "pp")
+    skip = ("enc_p.cond.", "enc_p.proj.", "w2v_encoder.project.", "w2v_encoder.proj.", "_codebook.inited",
+            "_codebook.cluster_size", "_codebook.embed_avg")
+    pick = lambda tops: [(k, s_) for k, s_ in shapes if k.split(".")[0] in tops and not any(x in k for x in skip)]
+    r = np.random.default_rng(77)
+
+    def rand_text(n):
+        ids = r.integers(1, 126, (1, n))
+        return ids, r.integers(0, 11, (1, n)), np.where(ids < 74, 1, np.where(ids < 113, 2, 0))
+
+    for case, ns, tms in [("ttv_front_n12", [12], [60]), ("ttv_front_b2", [20, 13], [70, 52])]:
+        B, Nm, Tm = len(ns), max(ns), max(tms)
+        ids, tone, lang = (np.zeros((B, Nm), np.int64) for _ in range(3))
+        mel = np.zeros((B, 80, Tm), np.float32)
+        per = []
+        for b, (n, tm) in enumerate(zip(ns, tms)):
+            ids[b, :n], tone[b, :n], lang[b, :n] = rand_text(n)
+            mel[b, :, :tm] = synth.synth_inputs(1, tm, seed=500 + n)["mel"][0]
+            a = (t(ids[b:b + 1, :n]), t(np.array([n])), t(mel[b:b + 1, :, :tm]), t(np.array([tm])), t(tone[b:b + 1, :n]),
+                 t(lang[b:b + 1, :n]))
+            xf, g, xl, xm = net.inf_extract_tc_latent(*a)
+            oxf, og, ofl, odur = O.ttv_extract_tc_latent_one(sd, a[0], a[2], a[4], a[5])
+            assert xm.dtype == torch.bool and int(xm.sum()) == xf.shape[2]
+            per.append((xf, g, xl.float(), oxf, og, torch.tensor([ofl]), odur))
+        T2 = max(p_[0].shape[2] for p_ in per)
+        pad = lambda x: F.pad(x, (0, T2 - x.shape[2]))
+        ref = [torch.cat([pad(p_[0]) for p_ in per]), torch.cat([p_[1] for p_ in per]), torch.cat([p_[2] for p_ in per])]
+        orc = [torch.cat([pad(p_[3]) for p_ in per]), torch.cat([p_[4] for p_ in per]), torch.cat([p_[5] for p_ in per])]
+        print(case, "durations", [p_[6].flatten().int().tolist() for p_ in per])
+        save(case, dict(kind="ttv_front", prefix="", seed=W, shapes=pick(front + gen)),
+             dict(ids=ids, tone=tone, language=lang, mel=mel, lengths=np.array(ns, np.int64),
+                  mel_lengths=np.array(tms, np.int64)), ref, orc)
+
+    for case, t2s in [("ttv_gen_t30", [30]), ("ttv_gen_b2", [41, 26])]:
+        B, T2 = len(t2s), max(t2s)
+        xf = rnd(600 + T2, B, 256, T2)
+        g = rnd(601 + T2, B, 256, 1)
+        codes = r.integers(0, 1024, (B, T2))
+        flen = np.array([n_ - 0.5 * (i % 2) for i, n_ in enumerate(t2s)], np.float32)   # x_lengths is frames / 2
+        w2v, lf0, ow2v, olf0 = (np.zeros(sh, np.float32) for sh in [(B, 1024, T2), (B, 4 * T2)] * 2)
+        for b, n in enumerate(t2s):
+            xm = (torch.arange(n).float() < float(flen[b])).view(1, 1, n)
+            wr, lr_ = net.inf_plm_gen(t(xf[b:b + 1, :, :n]), t(g[b:b + 1]), t(codes[b:b + 1, :n]).unsqueeze(1),
+                                      t(flen[b:b + 1]), xm)
+            w2v[b, :, :n], lf0[b, :4 * n] = wr[0].numpy(), lr_[0].numpy()
+            wo, lo = O.ttv_plm_gen_one(sd, t(xf[b:b + 1, :, :n]), t(g[b:b + 1]), t(codes[b:b + 1, :n]), float(flen[b]))
+            ow2v[b, :, :n], olf0[b, :4 * n] = wo[0].numpy(), lo[0].numpy()
+        for b, n in enumerate(t2s):   # frames past a length are zero in the fixture
+            xf[b, :, n:] = 0
+        save(case, dict(kind="ttv_gen", prefix="", seed=W, shapes=pick(front + gen)),
+             dict(x_frame=xf, g=g, codes=codes, frame_lengths=flen, lengths=np.array(t2s, np.int64)),
+             [t(w2v), t(lf0)], [t(ow2v), t(olf0)])
 
 
 # ----------------------------------------------------------------------------- cases
