@@ -264,6 +264,15 @@ int hsp_gaussian_upsample_f32(const float* x, int64_t x_bs, int64_t x_cs, const 
 int hsp_add_cbias_f32(const float* x, int64_t x_bs, int64_t x_cs, const float* cb, int64_t cb_bs, float* y,
                       int32_t B, int32_t C, int32_t T, void* stream);
 
+/* ------------------------------------------------ inference_plm.py:tts post-steps (row A19) */
+/* y[i] = x[i] < thr ? 0 : x[i] : pitch clipping `pitch[pitch < log(55)] = 0` (inference_plm.py:166) */
+int hsp_zero_below_f32(const float* x, float thr, float* y, int64_t n, void* stream);
+/* out[b, i] = (int16) (x[b, i] / max_j |x[b, j]| * 32767 * gain) over the first lengths[b] samples
+ * (NULL = all n), zeros after : `audio / max(abs(audio)) * 32767.0 * 0.999` then numpy
+ * astype('int16') (inference_plm.py:183-190) */
+int hsp_peak_int16(const float* x, int64_t x_bs, const int64_t* lengths, float gain, int16_t* out, int64_t o_bs,
+                   int32_t B, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

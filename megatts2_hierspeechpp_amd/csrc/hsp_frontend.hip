@@ -198,6 +198,41 @@ __global__ __launch_bounds__(256) void add_cbias_kernel(const float* __restrict_
   }
 }
 
+// y = x < thr ? 0 : x   (`pitch[pitch < log(55)] = 0`, inference_plm.py:166)
+__global__ __launch_bounds__(256) void zero_below_kernel(const float* __restrict__ x, float thr, float* __restrict__ y,
+                                                         int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float v = x[e];
+    y[e] = v < thr ? 0.0f : v;
+  }
+}
+
+// out[b, i] = (int16)(x[b, i] / max_j |x[b, j]| * 32767 * gain), j over the first len[b] samples; samples
+// past len[b] are 0.  Same operation order as inference_plm.py:186 and numpy's truncating astype(int16).
+__global__ __launch_bounds__(1024) void peak_int16_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                          const int64_t* __restrict__ len, float gain,
+                                                          int16_t* __restrict__ out, int64_t o_bs, int64_t n) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t L = len ? min(n, max((int64_t)0, len[b])) : n;
+  const float* xb = x + b * x_bs;
+  float mx = 0.0f;
+  for (int64_t i = tid; i < L; i += 1024) mx = fmaxf(mx, fabsf(xb[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  int16_t* ob = out + b * o_bs;
+  for (int64_t i = tid; i < n; i += 1024) {
+    float v = 0.0f;
+    if (i < L) v = xb[i] / mx * 32767.0f * gain;
+    ob[i] = (int16_t)fminf(fmaxf(v, -32768.0f), 32767.0f);
+  }
+}
+
 }  // namespace
 
 #define HSP_STREAM static_cast<hipStream_t>(stream)
@@ -252,5 +287,20 @@ extern "C" int hsp_add_cbias_f32(const float* x, int64_t x_bs, int64_t x_cs, con
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(add_cbias_kernel, dim3((unsigned)blocks), dim3(256), 0, HSP_STREAM, x, x_bs, x_cs, cb, cb_bs, y, B, C,
                      T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_zero_below_f32(const float* x, float thr, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return HSP_EINVAL;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_below_kernel, dim3((unsigned)blocks), dim3(256), 0, HSP_STREAM, x, thr, y, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_peak_int16(const float* x, int64_t x_bs, const int64_t* lengths, float gain, int16_t* out,
+                              int64_t o_bs, int32_t B, int64_t n, void* stream) {
+  if (!x || !out || B <= 0 || n <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(peak_int16_kernel, dim3((unsigned)B), dim3(1024), 0, HSP_STREAM, x, x_bs, lengths, gain, out, o_bs, n);
   return (int)hipGetLastError();
 }

@@ -382,12 +382,16 @@ class SynthesizerTrn(nn.Module):
     def voice_conversion_noise_control(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333,
                                        uncond=False, denoise_ratio=0, noise: Optional[torch.Tensor] = None):
         """:674-699.  trg_mel holds two prompts (original, denoised); their style vectors
-        are interpolated with ``denoise_ratio`` (B = 1 by construction)."""
+        are interpolated with ``denoise_ratio`` (B = 1 by construction in the reference, SURVEY.md
+        App. B1).  With B source utterances trg_mel is [2B, 80, T]: the B prompts, then the B denoised
+        prompts, and f0 is [B, 1, 4T]."""
         if uncond:
             raise NotImplementedError("uncond needs cfg=True")
+        B = src.shape[0]
+        assert trg_mel.shape[0] == 2 * B
         trg_mask = commons.sequence_mask(trg_length, trg_mel.size(2))
-        g = self.emb_g(trg_mel, trg_mask)  # [2, 256]
-        g = Fh.axpby(g[:1], g[1:], 1.0 - denoise_ratio, float(denoise_ratio)).unsqueeze(-1)
+        g = self.emb_g(trg_mel, trg_mask)  # [2B, 256]
+        g = Fh.axpby(g[:B], g[B:], 1.0 - denoise_ratio, float(denoise_ratio)).unsqueeze(-1)
         y_mask = commons.sequence_mask(src_length, src.size(2))
         z = self._latent(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
         return self._decode(z, g)[0]

@@ -1,0 +1,98 @@
+"""HIP mirror of the tensor core of the reference's inference_plm.py (its ``tts()`` between mel
+extraction and wav writing, :156-190, and the model bundle of ``model_load`` :203-263).
+
+Out of scope here (host plumbing, not the hot path): text cleaning / phonemisation
+(``get_text``), audio file IO and resampling, the mel spectrogram transform and the optional
+denoiser -- callers hand over phone ids and mels, exactly the tensors ``tts()`` feeds its models."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .hierspeechpp_speechsynthesizer import SynthesizerTrn
+from .hip_layers import finalize as _finalize
+from .ttv_v1.t2w2v_transformer import Megatts2PLM1
+from .ttv_v1.t2w2v_transformer import SynthesizerTrn as Text2W2V
+
+# text/symbols_lmdh.py: len(symbols), len(tone_symbols), len(language_symbols)
+N_VOCAB, N_TONE, N_LANGUAGE = 126, 11, 4
+
+
+class TtsModels(nn.Module):
+    """The ``hierspeech`` tuple of inference_plm.py:tts as one module: ``voc`` = net_g (the hierarchical
+    synthesizer), ``ttv`` = text2w2v, ``plm`` = the prosody LM, optional ``sr`` = SpeechSR.  One weight
+    arena for all of them -> one RCCL broadcast in a multi-GPU job."""
+
+    def __init__(self, voc_cfg: dict, ttv_cfg: dict, speechsr: Optional[nn.Module] = None):
+        super().__init__()
+        self.voc = SynthesizerTrn(641, 61440 // 320, **voc_cfg)
+        self.ttv = Text2W2V(N_VOCAB, N_TONE, N_LANGUAGE, 641, 320, 16000, 60, **ttv_cfg)
+        self.plm = Megatts2PLM1()
+        if speechsr is not None:
+            self.sr = speechsr
+
+    def finalize(self, device, materialize: bool = True):
+        self.arena = _finalize(self, device, materialize)
+        return self
+
+
+def zero_below(x, thr: float):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.lib().hsp_zero_below_f32(L.fptr(x), float(thr), L.fptr(y), x.numel(), L.stream_ptr()), "hsp_zero_below_f32")
+    return y
+
+
+def peak_int16(audio, lengths=None, gain: float = 0.999):
+    """[B, 1, n] / [B, n] fp32 -> int16 [B, n], every row scaled by its own peak (over ``lengths[b]`` samples)."""
+    a = audio.reshape(audio.shape[0], -1)
+    assert a.stride(1) == 1
+    out = torch.empty(a.shape, dtype=torch.int16, device=a.device)
+    L.check(L.lib().hsp_peak_int16(L.fptr(a), a.stride(0), L.ptr(lengths.to(torch.int64).contiguous()) if lengths is not None else None,
+                                   float(gain), L.ptr(out), out.stride(0), a.shape[0], a.shape[1], L.stream_ptr()),
+            "hsp_peak_int16")
+    return out
+
+
+@torch.no_grad()
+def tts(models: TtsModels, text, text_length, tone, language, src_mel_ttv, src_mel_ttv_length, src_mel, src_length2,
+        noise_scale_vc: float = 0.333, denoise_ratio: float = 0.0, output_sr: int = 16000, dur=None, noise=None,
+        return_float: bool = False):
+    """inference_plm.py:tts :156-190 on tensors.
+
+    text / tone / language int64 [B, N], text_length [B]; src_mel_ttv [B, 80, Tm'] (prompt mel for the
+    front-end) with lengths; src_mel [2B, 80, Tm] = the B prompt mels followed by the B denoised prompt
+    mels (the reference's ``torch.cat([audio, denoised])`` at B = 1) with ``src_length2`` [2B].
+    Returns int16 audio [B, n] (n = 320 * frames, x3 / x1.5 with SpeechSR), rows peak-normalised over
+    their own length.  B > 1 runs the utterances side by side; rows are independent up to the
+    vocoder, whose convolutions see a shorter row's zero padding exactly as the reference's own batched
+    ``infer`` does (equal-length batches are exact)."""
+    B = text.shape[0]
+    x_frame, g, x_lengths, x_mask = models.ttv.inf_extract_tc_latent(text, text_length, src_mel_ttv, src_mel_ttv_length,
+                                                                     tone, language, dur=dur)
+    codes = models.plm.infer(x_frame)
+    w2v_x, pitch = models.ttv.inf_plm_gen(x_frame, g, codes.unsqueeze(1) if B == 1 else codes, x_lengths, x_mask)
+    pitch = zero_below(pitch, math.log(55.0))                                  # :166 pitch clipping
+    T2 = w2v_x.shape[2]
+    if B == 1:
+        src_length = torch.full((1,), T2, dtype=torch.int64, device=w2v_x.device)   # :163 the whole padded length
+        audio = models.voc.voice_conversion_noise_control(w2v_x, src_length, src_mel, src_length2, pitch,
+                                                          noise_scale=noise_scale_vc, denoise_ratio=denoise_ratio,
+                                                          noise=noise)
+        n_valid = None
+    else:
+        frames = torch.ceil(x_lengths).to(torch.int64)
+        audio = models.voc.voice_conversion_noise_control(w2v_x, frames, src_mel, src_length2, pitch.unsqueeze(1),
+                                                          noise_scale=noise_scale_vc, denoise_ratio=denoise_ratio,
+                                                          noise=noise)
+        n_valid = frames * 320
+    if output_sr in (24000, 48000):
+        audio = models.sr(audio)
+        if n_valid is not None:
+            n_valid = n_valid * output_sr // 16000
+    wav = peak_int16(audio, n_valid)
+    return (wav, audio) if return_float else wav

@@ -105,6 +105,13 @@ def run_oracle(meta, arrays):
     if kind == "vc":
         return [O.synth_voice_conversion_noise_control(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"),
                                                        t("f0"), meta["noise_scale"], meta["denoise_ratio"], t("noise"))]
+    if kind == "tts_e2e":
+        sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        n, tm = arrays["ids"].shape[1], arrays["src_mel"].shape[2]
+        wav, audio = O.tts_one(sub("ttv."), {k: v for k, v in sd.items() if k.startswith("plm.")}, sub("voc."), cfg,
+                               t("ids"), t("tone"), t("language"), t("mel_ttv"), t("src_mel"),
+                               torch.tensor([tm, tm]), t("noise"), meta["noise_scale"], meta["denoise_ratio"])
+        return [audio, torch.from_numpy(wav.astype(np.float32))]
     if kind == "ttv_front":
         per = []
         for b, (n, tm) in enumerate(zip(arrays["lengths"], arrays["mel_lengths"])):
@@ -184,6 +191,9 @@ def build_module(meta):
     if kind == "plm":
         from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import Megatts2PLM1
         return Megatts2PLM1()
+    if kind == "tts_e2e":
+        from megatts2_hierspeechpp_amd.inference_plm import TtsModels
+        return TtsModels(cfg, TTV_MODEL)
     if kind in ("ttv_front", "ttv_gen"):
         from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import SynthesizerTrn as Text2W2V
         return Text2W2V(126, 11, 4, 641, 320, 16000, 60, **TTV_MODEL)
@@ -219,6 +229,15 @@ def run_hip(meta, arrays, device):
             out = [mod(d("x"), d("x"), mask_q=mask, mask_k=mask)]
         elif kind == "vits_encoder":
             out = [mod(d("x"), mask)]
+        elif kind == "tts_e2e":
+            from megatts2_hierspeechpp_amd.inference_plm import tts
+            n, tm = arrays["ids"].shape[1], arrays["src_mel"].shape[2]
+            dl = lambda v: torch.tensor(v, dtype=torch.int64, device=device)
+            wav, audio = tts(mod, d("ids"), dl([n]), d("tone"), d("language"), d("mel_ttv"),
+                             dl([arrays["mel_ttv"].shape[2]]), d("src_mel"), dl([tm, tm]),
+                             noise_scale_vc=meta["noise_scale"], denoise_ratio=meta["denoise_ratio"], noise=d("noise"),
+                             return_float=True)
+            out = [audio, wav.float().reshape(-1)]
         elif kind == "ttv_front":
             xf, g, fl, _ = mod.inf_extract_tc_latent(d("ids"), d("lengths"), d("mel"), d("mel_lengths"), d("tone"),
                                                      d("language"))

@@ -18,11 +18,14 @@ def test_oracle_matches_reference_golden(name):
         outs = H.run_oracle(meta, arrays)
     refs = H.outputs(arrays)
     assert len(outs) == len(refs)
-    for o, r in zip(outs, refs):
+    for i, (o, r) in enumerate(zip(outs, refs)):
         o = o.numpy()
         assert o.shape == r.shape
         # oracle == reference up to fp32 re-association (weight-norm fold order): well inside the 1e-4 bar
-        assert np.abs(o - r).max() <= 2e-5 * max(1.0, np.abs(r).max()), name
+        tol = 2e-5 * max(1.0, np.abs(r).max())
+        if meta["kind"] == "tts_e2e" and i == 1:
+            tol = 1.0   # int16 samples: fp32 re-association may move a value across an integer boundary (1 LSB)
+        assert np.abs(o - r).max() <= tol, name
 
 
 def test_act1d_closed_form_matches_oracle():

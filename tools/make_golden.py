@@ -110,6 +110,8 @@ def save(name, meta, arrays, ref_out, oracle_out):
         errs.append(err)
         assert r.shape == o.shape, (name, r.shape, o.shape)
         tol = ORACLE_TOL * max(1.0, r.abs().max().item())
+        if name == "tts_e2e" and i == 1:
+            tol = 1.0   # int16 samples: one LSB
         assert err <= tol, f"{name}: oracle deviates from reference by {err:g} (output {i})"
         arrays[f"out{i}"] = r.detach().numpy().astype(np.float32)
     meta["oracle_vs_reference_maxabs"] = errs
@@ -237,6 +239,46 @@ def ttv_cases():
         save(case, dict(kind="ttv_gen", prefix="", seed=W, shapes=pick(front + gen)),
              dict(x_frame=xf, g=g, codes=codes, frame_lengths=flen, lengths=np.array(t2s, np.int64)),
              [t(w2v), t(lf0)], [t(ow2v), t(olf0)])
+
+    # -- A19: the tensor core of inference_plm.py:tts (:156-190) -- front-end -> PLM -> w2v/pitch ->
+    #         pitch clipping -> voice_conversion_noise_control -> peak-normalised int16.  The call
+    #         sequence below is what tts() runs between mel extraction and wav writing (both file /
+    #         torchaudio plumbing, not on the hot path).
+    import math
+    import hierspeechpp_speechsynthesizer as HS
+    cfg = O.default_config()
+    voc = HS.SynthesizerTrn(641, 61440 // 320, **{k: v for k, v in cfg.items() if k != "gin_channels"})
+    vshapes, vsd = load_synth(voc, W, "voc.")
+    vused = [(k, s_) for k, s_ in vshapes if k.split(".")[0] in ("emb_g", "enc_p_l", "flow_l", "flow", "sn", "dec")]
+    tshapes, tsd = load_synth(net, W, "ttv.")
+    pshapes, psd = load_synth(mod, W, "plm.")
+    strip = lambda d, pre: {k[len(pre):]: v for k, v in d.items()}
+    n, tm = 10, 48
+    ids, tone, lang = rand_text(n)
+    mel_ttv = synth.synth_inputs(1, tm + 4, seed=900)["mel"]
+    src_mel = synth.synth_inputs(2, tm, seed=901)["mel"]
+    slen2 = np.array([tm, tm], np.int64)
+    xf, g, xl, xm = net.inf_extract_tc_latent(t(ids), t(np.array([n])), t(mel_ttv), t(np.array([tm + 4])), t(tone), t(lang))
+    codes = mod.infer(xf)
+    w2v_x, pitch = net.inf_plm_gen(xf, g, codes.unsqueeze(1), xl, xm)
+    src_length = torch.LongTensor([w2v_x.size(2)])
+    pitch[pitch < torch.log(torch.tensor([55.0]))] = 0
+    noise = rnd(902, 1, 192, w2v_x.size(2))
+    with FixedNoise(t(noise)):
+        audio = voc.voice_conversion_noise_control(w2v_x, src_length, t(src_mel), t(slen2), pitch, noise_scale=0.333,
+                                                   denoise_ratio=0.3)
+    a = audio.squeeze()
+    wav = (a / a.abs().max() * 32767.0 * 0.999).numpy().astype("int16")
+    owav, oaudio = O.tts_one(strip(tsd, "ttv."), {"plm." + k: v for k, v in strip(psd, "plm.").items()}, strip(vsd, "voc."),
+                             cfg, t(ids), t(tone), t(lang), t(mel_ttv), t(src_mel), t(slen2), t(noise), 0.333, 0.3)
+    lsb = int(np.abs(wav.astype(np.int32) - owav.astype(np.int32)).max())
+    print(f"tts_e2e: {wav.shape[0]} samples, oracle-vs-ref int16 max diff {lsb} LSB, pitch zeros {(pitch == 0).sum().item()}")
+    assert lsb <= 1
+    shapes_all = [("ttv." + k, s_) for k, s_ in pick(front + gen)] + [("plm." + k, s_) for k, s_ in pshapes] + \
+                 [("voc." + k, s_) for k, s_ in vused]
+    save("tts_e2e", dict(kind="tts_e2e", prefix="", seed=W, shapes=shapes_all, noise_scale=0.333, denoise_ratio=0.3),
+         dict(ids=ids, tone=tone, language=lang, mel_ttv=mel_ttv, src_mel=src_mel, noise=noise),
+         [audio, t(wav.astype(np.float32))], [oaudio, t(owav.astype(np.float32))])
 
 
 # ----------------------------------------------------------------------------- cases
