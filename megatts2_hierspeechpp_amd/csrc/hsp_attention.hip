@@ -152,13 +152,17 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
 constexpr int MQT = 32;
 typedef float mha_f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int n_qt, int sp) {
+// NDB = ceil(D / 32).  WHOLE_V: all of V (D x Tk) is staged in LDS once, next to the Q tile, so the kernel
+// has three global round trips in sequence (Q + V, the K fragments of this wave's key blocks, nothing else)
+// instead of one per 4 head-dim steps and two per 64-key slab: at T <= 256 the launch is pure latency.
+template <int NDB, bool WHOLE_V>
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int n_qt, int sp, int vp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = a.D, Tq = a.Tq, Tk = a.Tk;
-  const int DP = (D + 31) & ~31;
+  constexpr int DP = NDB * 32;
   float* Qs = lds;                 // [DP][32]  scale * q, zero rows beyond D
   float* S = Qs + DP * 32;         // [32][sp]
-  float* Vs = S + 32 * sp;         // [DP][65]
+  float* Vs = S + 32 * sp;         // WHOLE_V: [DP][vp] (vp odd, >= Tk rounded up to 64) ; else [DP][65]
   int bid = blockIdx.x;
   const int qt = bid % n_qt;
   bid /= n_qt;
@@ -173,28 +177,44 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
   const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
   float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
 
-  for (int e = tid; e < DP * 32; e += 256) {
+  if constexpr (WHOLE_V) {
+    // V rows straight into LDS (LDS-DMA, 4 B per lane, nothing waits here); padding is zeroed by hand
+    const int tkp = (Tk + 63) & ~63;
+    for (int d = wave; d < DP; d += 4)
+      for (int j0 = 0; j0 < tkp; j0 += 64) {
+        if (d < D && j0 + lane < Tk)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vh + (int64_t)d * vcs + j0 + lane),
+                                           (__attribute__((address_space(3))) void*)(Vs + d * vp + j0), 4, 0, 0);
+        else
+          Vs[d * vp + j0 + lane] = 0.0f;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < DP * 32 / 256; ++u) {
+    const int e = tid + 256 * u;
     const int i = e & 31, d = e >> 5;
     Qs[e] = (d < D && i0 + i < Tq) ? qh[(int64_t)d * qcs + i0 + i] * a.qk_scale : 0.0f;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- scores: wave w owns key blocks w, w+4, ...
+  // ---- scores: wave w owns key blocks w, w+4, ...; the block's K fragments are fetched in one batch
   const int nkb = (Tk + 31) >> 5;
-  const int d2 = DP >> 1;
   for (int jb = wave; jb < nkb; jb += 4) {
+    const int j = jb * 32 + l32;
+    const bool jok = j < Tk;
+    float kf[DP / 2];
+#pragma unroll
+    for (int kk = 0; kk < DP / 2; ++kk) {
+      const int d = 2 * kk + half;
+      kf[kk] = (jok && d < D) ? kh[(int64_t)d * kcs + j] : 0.0f;
+    }
     mha_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int j = jb * 32 + l32;
-    const bool jok = j < Tk;
-#pragma unroll 4
-    for (int kk = 0; kk < d2; ++kk) {
-      const int d = 2 * kk + half;
-      const float av = Qs[d * 32 + l32];
-      const float bv = (jok && d < D) ? kh[(int64_t)d * kcs + j] : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
+#pragma unroll
+    for (int kk = 0; kk < DP / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(2 * kk + half) * 32 + l32], kf[kk], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * half) * sp + j] = acc[r];
   }
@@ -231,27 +251,71 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
   mha_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int ndb = DP >> 5;
-  for (int j0 = 0; j0 < Tk; j0 += 64) {
-    __syncthreads();  // softmax complete (first slab) / previous slab consumed
-    for (int d = wave; d < DP; d += 4)
-      Vs[d * 65 + lane] = (d < D && j0 + lane < Tk) ? vh[(int64_t)d * vcs + j0 + lane] : 0.0f;
-    __syncthreads();
-    if (wave < ndb) {
-      const float* va = Vs + (wave * 32 + l32) * 65 + half;
-      const float* pb = S + l32 * sp + j0 + half;
+  if constexpr (WHOLE_V) {
+    __syncthreads();  // softmax rows complete
+    if (wave < NDB) {
+      const float* va = Vs + (wave * 32 + l32) * vp + half;
+      const float* pb = S + l32 * sp + half;
+      const int tk2 = (Tk + 1) & ~1;   // S and Vs are zero beyond Tk
 #pragma unroll 8
-      for (int jj = 0; jj < 64; jj += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[jj], pb[jj], acc, 0, 0, 0);
+      for (int jj = 0; jj < tk2; jj += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[jj], pb[jj], acc, 0, 0, 0);
+    }
+  } else {
+    for (int j0 = 0; j0 < Tk; j0 += 64) {
+      __syncthreads();  // softmax complete (first slab) / previous slab consumed
+      for (int d = wave; d < DP; d += 4)
+        Vs[d * 65 + lane] = (d < D && j0 + lane < Tk) ? vh[(int64_t)d * vcs + j0 + lane] : 0.0f;
+      __syncthreads();
+      if (wave < NDB) {
+        const float* va = Vs + (wave * 32 + l32) * 65 + half;
+        const float* pb = S + l32 * sp + j0 + half;
+#pragma unroll 8
+        for (int jj = 0; jj < 64; jj += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[jj], pb[jj], acc, 0, 0, 0);
+      }
     }
   }
-  if (wave < ndb && i0 + l32 < Tq) {
+  if (wave < NDB && i0 + l32 < Tq) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (d < D) oh[(int64_t)d * ocs + i0 + l32] = acc[r];
     }
   }
+}
+
+template <int NDB>
+int mha_mfma_launch(const hsp_mha_args& a, hipStream_t stream) {
+  constexpr int DP = NDB * 32;
+  const int sp = ((a.Tk + 31) & ~31) + 33;  // odd pitch, room for one zero slab column block
+  const int vp = ((a.Tk + 63) & ~63) + 1;
+  const int64_t base = ((int64_t)DP * 32 + 32 * (int64_t)sp) * (int64_t)sizeof(float);
+  const int64_t lds_whole = base + (int64_t)DP * vp * (int64_t)sizeof(float);
+  const int64_t lds_slab = base + (int64_t)DP * 65 * (int64_t)sizeof(float);
+  const bool whole = lds_whole <= 160 * 1024;
+  if (!whole && lds_slab > 160 * 1024) return -1;
+  const int n_qt32 = (a.Tq + MQT - 1) / MQT;
+  const unsigned blocks = (unsigned)((int64_t)n_qt32 * a.H * a.B);
+  if (whole) {
+    static std::atomic<int> cap{32 * 1024};
+    if (lds_whole > cap.load(std::memory_order_relaxed)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_mfma_kernel<NDB, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      cap.store(160 * 1024, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((mha_mfma_kernel<NDB, true>), dim3(blocks), dim3(256), (size_t)lds_whole, stream, a, n_qt32, sp, vp);
+  } else {
+    static std::atomic<int> cap{32 * 1024};
+    if (lds_slab > cap.load(std::memory_order_relaxed)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_mfma_kernel<NDB, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      cap.store(160 * 1024, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((mha_mfma_kernel<NDB, false>), dim3(blocks), dim3(256), (size_t)lds_slab, stream, a, n_qt32, sp, 65);
+  }
+  return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -269,22 +333,15 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   if ((a.rel_k || a.rel_v) && (a.window <= 0 || a.Tq != a.Tk)) return HSP_EINVAL;
   // matrix-core path: no relative-position window, head dim <= 128, scores of 32 queries fit LDS
   if (!a.rel_k && !a.rel_v && a.D <= 128) {
-    const int DP = (a.D + 31) & ~31;
-    const int sp = ((a.Tk + 31) & ~31) + 33;  // odd pitch, room for one zero slab column block
-    const int64_t lds_m = ((int64_t)DP * 32 + 32 * (int64_t)sp + (int64_t)DP * 65) * (int64_t)sizeof(float);
-    if (lds_m <= 160 * 1024) {
-      static std::atomic<int> cap{32 * 1024};
-      if (lds_m > cap.load(std::memory_order_relaxed)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_mfma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        cap.store(160 * 1024, std::memory_order_relaxed);
-      }
-      const int n_qt32 = (a.Tq + MQT - 1) / MQT;
-      hipLaunchKernelGGL(mha_mfma_kernel, dim3((unsigned)((int64_t)n_qt32 * a.H * a.B)), dim3(256), (size_t)lds_m,
-                         static_cast<hipStream_t>(stream), a, n_qt32, sp);
-      return (int)hipGetLastError();
+    const hipStream_t st = static_cast<hipStream_t>(stream);
+    int e = -1;
+    switch ((a.D + 31) / 32) {
+      case 1: e = mha_mfma_launch<1>(a, st); break;
+      case 2: e = mha_mfma_launch<2>(a, st); break;
+      case 3: e = mha_mfma_launch<3>(a, st); break;
+      default: e = mha_mfma_launch<4>(a, st); break;
     }
+    if (e >= 0) return e;
   }
   const int n_qt = (a.Tq + QT - 1) / QT;
   const int dpad = (a.D < 128 ? a.D : 128) | 1;

@@ -19,7 +19,10 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-graph", action="store_true")
+ap.add_argument("--debug", type=int, default=0, help="hsp_conv1d_args.debug for every conv launch (timing floors only)")
 args = ap.parse_args()
+from megatts2_hierspeechpp_amd import hip_layers  # noqa: E402
+hip_layers.DEBUG_FLAGS = args.debug
 dev = torch.device("cuda:0")
 m = Megatts2PLM1()
 m.load_state_dict({k: torch.from_numpy(synth.synth_tensor("plm." + k, tuple(v.shape), 7)) for k, v in m.state_dict().items()})
