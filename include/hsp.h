@@ -133,6 +133,14 @@ typedef struct hsp_conv1d_args {
   float post_scale;
   int32_t debug; /* 0 in production.  Tuning aids (results are then WRONG): bit 0 = producers
                     stage only the first chunk, bit 1 = consumers skip their MFMAs */
+  /* Fused input LayerNorm (1x1 token GEMMs only; any other shape is refused with HSP_EINVAL):
+   * y = W LN(x) + b with LN over the Cin channels of every column.  The caller packs
+   * w = W diag(gamma), bias = W beta + b and ln_c1[row] = sum_ci w[ci][row]; the kernel takes the
+   * column statistics from the staged input tile and applies
+   *   v = rstd[t] * (acc[m, t] - mean[t] * ln_c1[row]) + bias[row]      before the activation.
+   * nn.LayerNorm -> nn.Linear pairs of ttv_v1/transformer_mega.py:125-131.  NULL = off. */
+  const float* ln_c1;
+  float ln_eps;
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) implicit-GEMM path; stride must be 1,
@@ -217,7 +225,8 @@ int hsp_axpby_f32(const float* x, const float* z, float* y, float a, float b, in
  * SinePositionalEmbedding.forward (:510-514).  tc is channel-major with strides (tc_bs, tc_cs, 1);
  * codes is int64 [B, >= n] with row stride codes_bs and holds the go token at column 0;
  * pe_t is the sinusoid table transposed to [Dtc + Demb][P]; x has strides (x_bs, x_cs, 1):
- * (n, B*n) lays the batch side by side on the columns of one [D][B*n] matrix. */
+ * (n, B*n) lays the batch side by side on the columns of one [D][B*n] matrix; with x_bs == n and
+ * x_cs > B*n the columns [B*n, x_cs) of every row are zeroed (row padding to a multiple of 4). */
 int hsp_plm_embed_f32(const float* tc, int64_t tc_bs, int64_t tc_cs, int32_t Dtc, const int64_t* codes,
                       int64_t codes_bs, const float* emb, int32_t Demb, int32_t n_emb, const float* pe_t,
                       int32_t P, const float* alpha, float* x, int64_t x_bs, int64_t x_cs, int32_t B, int32_t n,

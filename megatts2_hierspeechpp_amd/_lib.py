@@ -42,6 +42,7 @@ class Conv1dArgs(C.Structure):
         ("cscale", _fp), ("cscale_bs", C.c_int64), ("scale", C.c_float),
         ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64),
         ("accumulate", C.c_int32), ("post_scale", C.c_float), ("debug", C.c_int32),
+        ("ln_c1", _fp), ("ln_eps", C.c_float),
     ]
 
 

@@ -33,6 +33,12 @@ __global__ __launch_bounds__(256) void plm_embed_kernel(const float* __restrict_
     }
     x[b * x_bs + c * x_cs + j] = fmaf(al, pe_t[(int64_t)c * P + j], v);
   }
+  // side-by-side layout (x_bs == n) with the row padded to x_cs > B*n columns: zero the padding
+  if (x_bs == n && x_cs > (int64_t)B * n) {
+    const int padc = (int)(x_cs - (int64_t)B * n);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < D * padc; e += gridDim.x * 256)
+      x[(int64_t)(e / padc) * x_cs + (int64_t)B * n + e % padc] = 0.0f;
+  }
 }
 
 // out[b * out_bs] = argmax_c logits[b * l_bs + c * l_cs]; ties -> lowest index (torch.argmax on CPU returns the

@@ -114,16 +114,33 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     };
     const int npre = nstage < TG_ST ? nstage : TG_ST;
     for (int s = 0; s < npre; ++s) issue(s);
+    float s1 = 0.0f, s2 = 0.0f;                         // fused LayerNorm: column sums of x and x^2
     for (int s = 0; s < nstage; ++s) {
       const int issued = (s + TG_ST < nstage ? s + TG_ST : nstage) - (s + 1);  // stages in flight behind s
       if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
       else if (issued == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tg_barrier();                                     // A_s: stage s is in LDS
+      if (a.ln_c1) {
+        // this wave's share of the stage's rows (pw, pw+4, ...), lane = column; padded rows are zero
+        const float* Xs = lds + (s % TG_ST) * STAGE + KS * TG_BM + lane;
+        const int rows = K - s * KS < KS ? K - s * KS : KS;
+        for (int r = pw; r < rows; r += 4) {
+          const float v = Xs[r * TG_BN];
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      }
       if (s + TG_ST < nstage) {
         tg_barrier();                                   // B_s: consumers are done with this slot
         if (!(a.debug & 1)) issue(s + TG_ST);
       }
+    }
+    if (a.ln_c1) {
+      float* st = lds + TG_ST * STAGE;                  // [4 producer waves][2][64]
+      st[(pw * 2 + 0) * 64 + lane] = s1;
+      st[(pw * 2 + 1) * 64 + lane] = s2;
+      tg_barrier();                                     // C: statistics are in LDS
     }
     return;
   }
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
   const int n = n0 + wn * 32 + l32;
   const int nc = n < a.ncols ? n : a.ncols - 1;
   const int mb = m0 + wm * 32 + 4 * half;
-  float bv[NR], rv[NR], yv[NR], cs[NR];
+  float bv[NR], rv[NR], yv[NR], cs[NR], c1[NR];
   const float mk = a.mask_mode != HSP_MASK_NONE ? a.mask[(int64_t)b * a.mask_bs + nc] : 1.0f;
   const float* resb = a.res ? a.res + (int64_t)b * a.res_bs + nc : nullptr;
   float* yb = a.y + (int64_t)b * a.y_bs + nc;
@@ -155,6 +172,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     cs[i] = a.cscale ? a.cscale[(int64_t)b * a.cscale_bs + mc] : 1.0f;
     rv[i] = resb ? resb[(int64_t)mc * a.res_cs] : 0.0f;
     yv[i] = a.accumulate ? yb[(int64_t)mc * a.y_cs] : 0.0f;
+    c1[i] = a.ln_c1 ? a.ln_c1[mc] : 0.0f;
   }
   float A0[4], B0[4], A1[4], B1[4];
   for (int s = 0; s < nstage; ++s) {
@@ -173,6 +191,18 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[2 * kk * TG_BM], Xs[2 * kk * TG_BN], acc, 0, 0, 0);
     }
     if (s + TG_ST < nstage) tg_barrier();               // B_s
+  }
+
+  // ---- fused LayerNorm: mean / rstd of this lane's column from the producers' partial sums
+  float mean = 0.0f, rstd = 1.0f;
+  if (a.ln_c1) {
+    tg_barrier();                                       // C
+    const float* st = lds + TG_ST * STAGE + wn * 32 + l32;
+    const float t1 = (st[0 * 64] + st[2 * 64]) + (st[4 * 64] + st[6 * 64]);
+    const float t2 = (st[1 * 64] + st[3 * 64]) + (st[5 * 64] + st[7 * 64]);
+    mean = t1 / (float)K;
+    const float var = fmaxf(t2 / (float)K - mean * mean, 0.0f);
+    rstd = 1.0f / sqrtf(var + a.ln_eps);
   }
 
   // ---- SPLIT: combine the two K-groups.  Each finalises 8 of the 16 accumulator rows and hands the other 8
@@ -199,7 +229,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     const int r = NR * grp + i;
     const int m = mb + (r & 3) + 8 * (r >> 2);
     if (m >= a.Cout) continue;
-    float v = hsp_apply_act(fin[i] + bv[i], a.act);     // same order as hsp_epilogue_store
+    float v = a.ln_c1 ? fmaf(rstd, fmaf(-mean, c1[i], fin[i]), bv[i]) : fin[i] + bv[i];
+    v = hsp_apply_act(v, a.act);                        // then the order of hsp_epilogue_store
     if (a.mask_mode & HSP_MASK_PRE) v *= mk;
     v *= cs[i];
     v *= a.scale;
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
 template <bool SPLIT>
 int tg_launch(const hsp_conv1d_args& a, hipStream_t s, int n_mt, int n_nt, int64_t blocks) {
   constexpr int KS = SPLIT ? 2 * TG_KH : TG_KH;
-  const size_t lds_bytes = (size_t)TG_ST * KS * (TG_BM + TG_BN) * sizeof(float);
+  const size_t lds_bytes = (size_t)TG_ST * KS * (TG_BM + TG_BN) * sizeof(float) + 2048;  // + LayerNorm partials
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_kernel<SPLIT>),
@@ -235,6 +266,7 @@ int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s) {
   if (a.x_ts != 1 || a.Lin != a.ncols || a.Lout != a.ncols) return -1;
   if ((a.Cin & 3) || (a.ncols & 3) || (a.x_bs & 3) || (a.x_cs & 3) || !al16(a.x) || !al16(a.w) || (a.w_ld & 3)) return -1;
   if (a.Cin < 64 || a.Cin > 4096) return -1;
+  if (a.ln_c1 && !(a.ln_eps > 0.0f)) return -1;
   const int n_mt = (a.M + TG_BM - 1) / TG_BM, n_nt = (a.ncols + TG_BN - 1) / TG_BN;
   const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
   if (blocks <= 0 || blocks > 0x7fffffff) return -1;

@@ -199,15 +199,44 @@ class Conv1d(_ConvBase):
             self.row_map = plain_rows(cout)
         self.M = int(self.row_map.shape[0])
 
+    def fuse_input_layernorm(self, norm):
+        """Run ``norm`` (an affine LayerNorm over the input channels: attributes ``weight``/``gamma``,
+        ``bias``/``beta``, ``eps``) inside this 1x1 layer's GEMM: the packed weight becomes W diag(gamma), the
+        bias W beta + b, and ``ln_c1`` the row sums of the packed weight (hsp_conv1d_args.ln_c1).  The layer is
+        then called on the UN-normalised input."""
+        assert self.k == 1 and self.rows == L.ROWS_PLAIN
+        self.__dict__["_pre_norm"] = norm   # not registered: the norm stays where the reference keeps it
+
+    def _ln_params(self):
+        n = self._pre_norm
+        g = (n.weight if hasattr(n, "weight") else n.gamma).data
+        b = (n.bias if hasattr(n, "weight") else n.beta).data
+        return g, b
+
     def hsp_requests(self):
-        return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias else [])
+        fused = self.__dict__.get("_pre_norm") is not None
+        return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias or fused else []) + \
+            ([("c1", self.cout)] if fused else [])
 
     def hsp_fill(self, arena, materialize):
+        fused = self.__dict__.get("_pre_norm") is not None
         self._w = arena.view(self, "w")
-        self._b = arena.view(self, "b") if self.has_bias else None
+        self._b = arena.view(self, "b") if self.has_bias or fused else None
+        self._c1 = arena.view(self, "c1") if fused else None
         if materialize:
-            _gather(self._folded(), conv_pack_map(self.cout, self.cin, self.k, self.row_map), self._w)
-            if self._b is not None:
+            w = self._folded()
+            if fused:
+                g, beta = self._ln_params()
+                w2 = w.reshape(self.cout, self.cin).double()
+                wg = w2 * g.double()[None, :]
+                self._c1.copy_(wg.sum(1).float())
+                c2 = w2 @ beta.double()
+                if self.has_bias:
+                    c2 = c2 + self._bias_src().double()
+                self._b.copy_(c2.float())
+                w = wg.float().reshape(w.shape).contiguous()
+            _gather(w, conv_pack_map(self.cout, self.cin, self.k, self.row_map), self._w)
+            if self._b is not None and not fused:
                 self._b.copy_(self._bias_src())
 
     # ----------------------------------------------------------------------------
@@ -248,8 +277,11 @@ class Conv1d(_ConvBase):
             a.prologue, a.slope = L.PRO_LRELU, float(lrelu)
         elif silu_in:
             a.prologue = L.PRO_SILU
+        if self.__dict__.get("_pre_norm") is not None:
+            a.ln_c1, a.ln_eps = L.fptr(self._c1), float(self._pre_norm.eps)
+            assert not force_direct and row_range is None
         direct = (force_direct or self.stride != 1 or self.cin < 8 or cout < 8 or Lout < 8 or silu_in) \
-            and not gated and act1d is None
+            and not gated and act1d is None and self.__dict__.get("_pre_norm") is None
         rows_full = cout * (2 if gated else 1)
         flops = 2 * B * rows_full * Cin * self.k * Lout
         # algorithmic traffic: input once, output once (+ residual / accumulate reads), weights once

@@ -102,13 +102,14 @@ class Megatts2PLM1(nn.Module):
         return self
 
     def _embed(self, tc, codes, n):
-        """[1, d_model, B*n]: utterance b occupies columns b*n .. b*n+n-1."""
+        """[1, d_model, Np]: utterance b occupies columns b*n .. b*n+n-1; Np = B*n rounded up to a multiple
+        of 4 (16-B rows for the token GEMM's DMA), padding columns are zero."""
         B = tc.shape[0]
-        x = torch.empty(1, self.d_model, B * n, dtype=torch.float32, device=tc.device)
+        x = torch.empty(1, self.d_model, (B * n + 3) & ~3, dtype=torch.float32, device=tc.device)
         L.check(L.lib().hsp_plm_embed_f32(L.fptr(tc), tc.stride(0), tc.stride(1), self.tc_latent_dim, L.ptr(codes),
                                           codes.stride(0), L.fptr(self.pc_embedding._w), self.vq_dim,
                                           self.pc_embedding.num_embeddings, L.fptr(self.pos_emb._pe_t),
-                                          self.pos_emb.N_POS, L.fptr(self.pos_emb._alpha), L.fptr(x), n, B * n, B, n,
+                                          self.pos_emb.N_POS, L.fptr(self.pos_emb._alpha), L.fptr(x), n, x.shape[2], B, n,
                                           L.stream_ptr()), "hsp_plm_embed_f32")
         return x
 
@@ -116,7 +117,12 @@ class Megatts2PLM1(nn.Module):
         """Logits of position n-1 given the first n columns of ``tc_latent`` [B, 256, T] and of
         ``codes`` [B, >= n] (go token first): one pass of the loop body (:710-716) -> [1, vq_bins, B]."""
         B = tc_latent.shape[0]
-        x = self.plm(self._embed(tc_latent, codes, n), batch=(B, n), last_only=True)
+        # the last layer only produces the last position of every utterance when those B columns form a
+        # 16-B addressable matrix for the fused-LayerNorm GEMM; otherwise it runs in full
+        last_only = B % 4 == 0
+        x = self.plm(self._embed(tc_latent, codes, n), batch=(B, n), last_only=last_only)
+        if not last_only:
+            x = Fh.copy_strided(x[0][:, :B * n].reshape(self.d_model, B, n)[:, :, n - 1].unsqueeze(0))
         return self.predict_layer(x, out=out)
 
     @torch.no_grad()

@@ -47,7 +47,9 @@ class MultiHeadAttention(nn.Module):
     """transformer_mega.MultiHeadAttention (:44-87), self-attention without a mask (the only form
     Megatts2PLM1.infer uses: ``self.plm(x_pos)`` passes no lengths, t2w2v_transformer.py:715)."""
 
-    def __init__(self, qkv_dim, n_heads=8, dropout=0.):
+    def __init__(self, qkv_dim, n_heads=8, dropout=0., pre_norm=None):
+        """``pre_norm``: the LayerNorm the encoder layer applies to this module's input; it is folded into
+        the stacked q/k/v GEMM (hsp_conv1d_args.ln_c1) and ``forward`` then takes the un-normalised x."""
         super().__init__()
         assert qkv_dim % n_heads == 0
         self.n_heads, self.head_dim, self.qkv_dim = n_heads, qkv_dim // n_heads, qkv_dim
@@ -55,6 +57,8 @@ class MultiHeadAttention(nn.Module):
         self.w_k = LinearCT(qkv_dim, qkv_dim, packed=False)
         self.w_v = LinearCT(qkv_dim, qkv_dim, packed=False)
         self.qkv = StackedLinearCT([self.w_q, self.w_k, self.w_v])
+        if pre_norm is not None:
+            self.qkv.fuse_input_layernorm(pre_norm)
         self.out_proj = nn.ModuleList([LinearCT(qkv_dim, qkv_dim)])  # nn.Sequential(Linear, Dropout): key "out_proj.0"
 
     def forward(self, x, kv=None, mask=None, res=None, batch=None, last_only=False):
@@ -65,13 +69,15 @@ class MultiHeadAttention(nn.Module):
         D = self.qkv_dim
         B, T = batch if batch is not None else (x.shape[0], x.shape[2])
         qkv = self.qkv(x)
-        o = torch.empty_like(x)
-        per_utt = lambda m: m.reshape(-1, B, T).permute(1, 0, 2) if batch is not None else m  # [B, C, T] view
+        # padding columns (odd batch sizes only) must stay finite: they flow through the following GEMMs
+        o = torch.empty_like(x) if batch is None or x.shape[2] == B * T else torch.zeros_like(x)
+        # [B, C, T] view of a [C, Np] matrix (Np >= B*T: rows may be padded to a multiple of 4 columns)
+        per_utt = lambda m: m[:, :B * T].reshape(-1, B, T).permute(1, 0, 2) if batch is not None else m
         q, k, v = (per_utt(qkv[0, i * D:(i + 1) * D]) if batch is not None else qkv[:, i * D:(i + 1) * D]
                    for i in range(3))
         Fh.mha(q, k, v, self.n_heads, 1.0 / math.sqrt(self.head_dim), out=per_utt(o[0]) if batch is not None else o)
         if last_only:
-            o = o[0].reshape(D, B, T)[:, :, T - 1].unsqueeze(0)  # [1, D, B] view, time stride T
+            o = o[0][:, :B * T].reshape(D, B, T)[:, :, T - 1].unsqueeze(0)  # [1, D, B] view, time stride T
         return self.out_proj[0](o, res=res)
 
 
@@ -85,9 +91,11 @@ class TransformerEncoderLayer(nn.Module):
         self.dim, self.ff_dim, self.conv_ff, self.n_heads = dim, ff_dim, conv_ff, n_heads
         self.norm1 = LayerNorm(dim)
         self.norm2 = LayerNorm(dim)
-        self.attn = MultiHeadAttention(dim, n_heads=n_heads, dropout=dropout)
+        # both LayerNorms run inside the GEMM that consumes them (statistics from the staged input tile)
+        self.attn = MultiHeadAttention(dim, n_heads=n_heads, dropout=dropout, pre_norm=self.norm1)
         # nn.Sequential(Linear, ReLU, Dropout, Linear): keys "ff.0" and "ff.3"
         self.ff = nn.ModuleDict({"0": LinearCT(dim, ff_dim), "3": LinearCT(ff_dim, dim)})
+        self.ff["0"].fuse_input_layernorm(self.norm2)
 
     def forward(self, x, mask=None, batch=None, last_only=False):
         """``last_only`` returns just the last position of every utterance ``[1, D, B]`` (all the
@@ -95,9 +103,9 @@ class TransformerEncoderLayer(nn.Module):
         res = x
         if last_only:
             B, T = batch
-            res = Fh.copy_strided(x[0].reshape(-1, B, T)[:, :, T - 1].unsqueeze(0))
-        x = self.attn(self.norm1(x), mask=mask, res=res, batch=batch, last_only=last_only)
-        h = self.ff["0"](self.norm2(x), act=L.ACT_RELU)
+            res = Fh.copy_strided(x[0][:, :B * T].reshape(-1, B, T)[:, :, T - 1].unsqueeze(0))
+        x = self.attn(x, mask=mask, res=res, batch=batch, last_only=last_only)   # norm1 fused into q/k/v
+        h = self.ff["0"](x, act=L.ACT_RELU)                                       # norm2 fused into ff.0
         return self.ff["3"](h, res=x)
 
 

@@ -340,3 +340,27 @@ def test_tts_batch_rows_match_single_runs(device):
                         torch.cat([ml[s], ml[s]]), dur=dur[s], noise=noise[s], return_float=True)
         assert float((a1[0] - audio[b]).abs().max()) < 5e-5
         assert int((w1[0].int() - wav[b].int()).abs().max()) <= 3
+
+
+def test_fused_layernorm_gemm_vs_torch(device):
+    """hsp_conv1d_args.ln_c1: y = W LN(x) + b with the LayerNorm folded into the token GEMM (statistics from the
+    staged input tile) against torch's two-pass LayerNorm + Linear; also that shapes outside the token-GEMM path
+    are refused instead of silently dropping the norm."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.hip_layers import LinearCT, finalize
+    from megatts2_hierspeechpp_amd.ttv_v1.transformer_mega import LayerNorm
+    g = torch.Generator().manual_seed(21)
+    for cin, cout, N in [(276, 828, 48), (276, 1104, 3200), (192, 64, 20)]:
+        norm, lin = LayerNorm(cin), LinearCT(cin, cout)
+        gamma, beta = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+        w, b = torch.randn(cout, cin, generator=g) / cin ** 0.5, 0.1 * torch.randn(cout, generator=g)
+        norm.weight.data, norm.bias.data, lin.weight.data, lin.bias.data = gamma.clone(), beta.clone(), w.clone(), b.clone()
+        lin.fuse_input_layernorm(norm)
+        holder = torch.nn.ModuleList([norm, lin])
+        finalize(holder, device)
+        x = 3.0 * torch.randn(1, cin, N, generator=g) + 1.5          # non-zero mean: exercises E[x^2] - mean^2
+        ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.transpose(1, 2), (cin,), gamma, beta, 1e-5), w, b)
+        got = lin(x.to(device), act=L.ACT_RELU).cpu()
+        _close(got.numpy(), torch.relu(ref).transpose(1, 2).numpy(), f"ln+gemm {cin}->{cout} N={N}")
+    with pytest.raises(L.HspError):
+        lin(torch.randn(1, 192, 18).to(device))                     # 18 columns: rows are not 16-B addressable
