@@ -143,13 +143,15 @@ typedef struct hsp_conv1d_args {
   float ln_eps;
 } hsp_conv1d_args;
 
-/* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) implicit-GEMM path; stride must be 1,
- * M % 4 == 0.  `lds_bytes_out`, if non-NULL, receives the dynamic LDS size used. */
+/* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Two kernels sit
+ * behind this entry point: the implicit-GEMM conv kernel (any K / dilation / prologue / row mode) and,
+ * for 1x1 convs over a short column axis (or with ln_c1), the latency-oriented token GEMM. */
 int hsp_conv1d_mfma_f32(const hsp_conv1d_args* a, void* stream);
 /* VALU path: any shape (Cin = 1, Cout = 1, stride > 1, L = 1 "Linear" cases);
  * rows must be PLAIN; prologue NONE/LRELU/SILU. */
 int hsp_conv1d_direct_f32(const hsp_conv1d_args* a, void* stream);
-/* which tile configuration hsp_conv1d_mfma_f32 would pick: writes BM, BN, KC, LDS bytes */
+/* which kernel / tile configuration hsp_conv1d_mfma_f32 would pick: writes BM, BN, KC, LDS bytes
+ * (KC = 0: the token-GEMM kernel) */
 int hsp_conv1d_mfma_plan(const hsp_conv1d_args* a, int32_t out4[4]);
 
 /* ------------------------------------------------------- anti-aliased activation */

@@ -35,7 +35,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s);  // hsp_tokgemm.hip; -1 = shape not taken
+int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);  // hsp_tokgemm.hip; -1 = shape not taken
 
 namespace {
 
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
                   va += a.cbias[(int64_t)b * a.cbias_bs + co];
                   vb += a.cbias[(int64_t)b * a.cbias_bs + H + co];
                 }
-                const float v = (a.rows == HSP_ROWS_GATE_WN ? tanhf(va) : va) * hsp_sigmoid(vb);
+                const float v = (a.rows == HSP_ROWS_GATE_WN ? hsp_tanh(va) : va) * hsp_sigmoid(vb);
                 hsp_epilogue_store(a, b, co, t, v);
               }
             });
@@ -735,9 +735,9 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // "short": even 128 x 128 tiles would leave CUs idle; prefer small tiles with deep chunks so
   // that every CU gets work and each tile sees few global-load round trips
   const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B < 256;
-  if ((short_seq || a.ln_c1) && !plan_out && !(a.debug & 128)) {
+  if ((short_seq || a.ln_c1) && !(a.debug & 128)) {
     // 1x1 GEMMs over a few thousand token columns: the latency-oriented kernel (hsp_tokgemm.hip)
-    const int e = hsp_tokgemm_try(a, s);
+    const int e = hsp_tokgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
   if (a.ln_c1) return HSP_EINVAL;  // the fused input LayerNorm exists on the token-GEMM path only

@@ -8,12 +8,21 @@
 
 __device__ __forceinline__ float hsp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 (v_exp_f32) and a true division: ~12 instructions
+// instead of ocml tanhf's ~100 (which dominated the GELU / WN-gate epilogues).  Absolute error < 2e-7
+// (exp2 is accurate to 1 ulp; the subtraction from 1 bounds the error by ulp(1)); saturates to +-1 cleanly
+// for large |x| (exp -> inf / 0).
+__device__ __forceinline__ float hsp_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x) = 2^(2x log2 e)
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
 __device__ __forceinline__ float hsp_apply_act(float v, int act) {
   switch (act) {
-    case HSP_ACT_TANH: return tanhf(v);
+    case HSP_ACT_TANH: return tanhf(v);   // final waveform tanh: full precision
     case HSP_ACT_GELU_TANH: {
       const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-      return 0.5f * v * (1.0f + tanhf(k0 * (v + k1 * v * v * v)));
+      return 0.5f * v * (1.0f + hsp_tanh(k0 * (v + k1 * v * v * v)));
     }
     case HSP_ACT_RELU: return fmaxf(v, 0.0f);
     case HSP_ACT_MISH: {

@@ -260,7 +260,7 @@ int tg_launch(const hsp_conv1d_args& a, hipStream_t s, int n_mt, int n_nt, int64
 
 // Host side: eligibility + launch; called by the conv dispatcher (hsp_conv1d_mfma.hip).
 // Returns -1 when the shape is not one this kernel takes.
-int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s) {
+int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (a.K != 1 || a.stride != 1 || a.pad != 0 || a.prologue != HSP_PRO_NONE || a.rows != HSP_ROWS_PLAIN) return -1;
   if (a.x_ts != 1 || a.Lin != a.ncols || a.Lout != a.ncols) return -1;
@@ -272,5 +272,10 @@ int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s) {
   if (blocks <= 0 || blocks > 0x7fffffff) return -1;
   // up to one tile per CU: halve each tile's serial chain; beyond: two resident tiles per CU
   const bool split = (a.debug & 256) ? true : ((a.debug & 512) ? false : blocks <= 256);
+  if (plan_out) {  // {BM, BN, 0 = "token GEMM" (the conv kernel reports its chunk depth here), LDS bytes}
+    plan_out[0] = TG_BM; plan_out[1] = TG_BN; plan_out[2] = 0;
+    plan_out[3] = (int32_t)((size_t)TG_ST * (split ? 2 : 1) * TG_KH * (TG_BM + TG_BN) * sizeof(float) + 2048);
+    return 0;
+  }
   return split ? tg_launch<true>(a, s, n_mt, n_nt, blocks) : tg_launch<false>(a, s, n_mt, n_nt, blocks);
 }

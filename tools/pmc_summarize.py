@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r01_traffic.json
+(KB summed per kernel class; bench.py reads conv1d_mfma_bytes_per_step for `roofline.traffic`).
+    python tools/pmc_summarize.py gpurun_out profiles/r01_traffic.json"""
+import csv
+import glob
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+CLASSES = ["conv1d_mfma_kernel", "tokgemm_kernel", "act1d_kernel", "mha_mfma_kernel", "mha_kernel", "layernorm",
+           "conv1d_direct_kernel"]
+
+
+def cls(name):
+    for c in CLASSES:
+        if c in name:
+            return c
+    return "other"
+
+
+out = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(f"{src}/traffic_{counter}/**/*counter_collection.csv", recursive=True)
+    assert files, f"no counter csv for {counter}"
+    for row in csv.DictReader(open(sorted(files)[-1])):
+        if row["Counter_Name"] != counter:
+            continue
+        k = out.setdefault(cls(row["Kernel_Name"]), {"launches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
+        k[f"{counter}_KB"] += float(row["Counter_Value"])
+        if counter == "FETCH_SIZE":
+            k["launches"] += 1
+steps = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
+conv = out["conv1d_mfma_kernel"]
+res = {
+    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-graph "
+            "--no-roofline` (= 2 executed steps); values are KB summed over all launches of a kernel class; "
+            "calibration on a known case (conv 128->128 k3, L=16000, B=8, no activation: 65.5 MB out, ~66.8 MB in): "
+            "WRITE_SIZE exact, FETCH_SIZE 0.90 of the expected bytes for the 4-B/lane LDS-DMA window reads, so no "
+            "correction is applied",
+    "steps_in_run": steps, "batch_per_gpu": 32, "frames": 200, "kernels": out,
+    "conv1d_mfma_bytes_per_step": (conv["FETCH_SIZE_KB"] + conv["WRITE_SIZE_KB"]) * 1024 / steps,
+    "conv1d_mfma_launches_per_step": conv["launches"] / steps,
+}
+json.dump(res, open(dst, "w"), indent=1)
+print({k: res[k] for k in ("conv1d_mfma_bytes_per_step", "conv1d_mfma_launches_per_step")})
