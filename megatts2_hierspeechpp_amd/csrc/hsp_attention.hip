@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
   __syncthreads();
 
   // ---- scores: wave w owns key blocks w, w+4, ...; the block's K fragments are fetched in one batch
+  // (issuing the first block's fragments together with the Q / V reads saves 1.2 us at T <= 128 but costs
+  //  more than that once two workgroups share a CU: measured, not kept)
   const int nkb = (Tk + 31) >> 5;
   for (int jb = wave; jb < nkb; jb += 4) {
     const int j = jb * 32 + l32;
@@ -220,7 +222,9 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
   }
   __syncthreads();
 
-  // ---- row softmax over the Tk valid keys (8 rows per wave); padding columns become 0
+  // ---- row softmax over the Tk valid keys (8 rows per wave).  exp on the hardware exp2; the 1 / sum
+  // normalisation is applied to the PV output (queries sit on the lanes there), padding columns become 0
+  float* inv_s = Qs;   // Qs is dead after the score phase (all waves passed the barrier above): 32 floats reused
   for (int u = 0; u < 8; ++u) {
     const int row_i = wave * 8 + u;
     float* row = S + row_i * sp;
@@ -236,15 +240,14 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sum = 0.0f;
-    for (int j = lane; j < Tk; j += 64) {
-      const float e = expf(row[j] - mx);
+    for (int j = lane; j < nkb * 32 + 32 && j < sp; j += 64) {
+      const float e = j < Tk ? __builtin_amdgcn_exp2f((row[j] - mx) * 1.4426950408889634f) : 0.0f;
       row[j] = e;
       sum += e;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float inv = 1.0f / sum;
-    for (int j = lane; j < nkb * 32 + 32 && j < sp; j += 64) row[j] = j < Tk ? row[j] * inv : 0.0f;
+    if (lane == 0) inv_s[row_i] = 1.0f / sum;
   }
 
   // ---- O^T = V P^T: wave w owns head-dim block w (D <= 128)
@@ -276,10 +279,11 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
     }
   }
   if (wave < NDB && i0 + l32 < Tq) {
+    const float inv = inv_s[l32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = acc[r];
+      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = acc[r] * inv;
     }
   }
 }
@@ -292,10 +296,12 @@ int mha_mfma_launch(const hsp_mha_args& a, hipStream_t stream) {
   const int64_t base = ((int64_t)DP * 32 + 32 * (int64_t)sp) * (int64_t)sizeof(float);
   const int64_t lds_whole = base + (int64_t)DP * vp * (int64_t)sizeof(float);
   const int64_t lds_slab = base + (int64_t)DP * 65 * (int64_t)sizeof(float);
-  const bool whole = lds_whole <= 160 * 1024;
-  if (!whole && lds_slab > 160 * 1024) return -1;
   const int n_qt32 = (a.Tq + MQT - 1) / MQT;
   const unsigned blocks = (unsigned)((int64_t)n_qt32 * a.H * a.B);
+  // whole-V needs one round trip less per 64 keys but more LDS: with more workgroups than CUs prefer the
+  // footprint that lets two of them share a CU (their latencies then overlap instead of queueing)
+  const bool whole = lds_whole <= 160 * 1024 && (blocks <= 256 || lds_whole <= 80 * 1024 || lds_slab > 80 * 1024);
+  if (!whole && lds_slab > 160 * 1024) return -1;
   if (whole) {
     static std::atomic<int> cap{32 * 1024};
     if (lds_whole > cap.load(std::memory_order_relaxed)) {
