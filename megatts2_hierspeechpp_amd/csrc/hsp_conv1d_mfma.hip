@@ -723,6 +723,8 @@ using M256W8 = Cfg<4, 2, 2, 2, 4, 3>;  // 256 x 128, eight consumer waves (two p
 using M128 = Cfg<2, 2, 2, 2, 4, 4>;    // 128 x 128, two workgroups per CU
 using M64 = Cfg<1, 4, 2, 2, 8, 3>;     //  64 x 256
 using M32 = Cfg<1, 4, 1, 4, 8, 3>;     //  32 x 512
+using M64P = Cfg<1, 4, 2, 2, 4, 4>;    //  64 x 256, plain prologue: four producer waves, two workgroups per CU
+using M32P = Cfg<1, 4, 1, 4, 4, 4>;    //  32 x 512, likewise
 using S64 = Cfg<2, 2, 1, 1, 4, 2>;     //  64 x 64   short sequences: many small, deep-chunk tiles
 using S64G = Cfg<1, 4, 2, 1, 4, 2>;    //  64 x 128  short sequences, gated rows (needs TM even)
 using S32 = Cfg<1, 4, 1, 1, 4, 2>;     //  32 x 128
@@ -746,10 +748,22 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     if (a.M > 32) return launch<S64>(a, s, plan_out);
     return launch<S32>(a, s, plan_out);
   }
-  if (a.M > 128) return launch<M256>(a, s, plan_out);
+  if (a.debug & 256) return launch<M128>(a, s, plan_out);   // tuning: force a tile shape (results stay right)
+  if (a.debug & 512) return launch<M256W8>(a, s, plan_out);
+  if (a.debug & 1024) return launch<M64>(a, s, plan_out);
+  if (a.M > 128) {
+    // 256 x 128 tiles run one per CU, 128 x 128 tiles two per CU at half the work each: in units of
+    // one 128 x 128 tile's MFMA time a CU spends 2 ceil(n256 / 256) against ceil(n128 / 256).
+    // The small tile wins whenever the large one leaves CUs idle (SourceNetwork, L = 400).
+    const int64_t nt = (a.ncols + 127) / 128;
+    const int64_t n256 = (int64_t)((a.M + 255) / 256) * nt * a.B, n128 = (int64_t)((a.M + 127) / 128) * nt * a.B;
+    if ((n128 + 255) / 256 < 2 * ((n256 + 255) / 256)) return launch<M128>(a, s, plan_out);
+    return launch<M256>(a, s, plan_out);
+  }
   if (a.M > 64) return launch<M128>(a, s, plan_out);
-  if (a.M > 32) return launch<M64>(a, s, plan_out);
-  return launch<M32>(a, s, plan_out);
+  const bool plain_in = a.prologue != HSP_PRO_ACT1D && !(a.debug & 2048);
+  if (a.M > 32) return plain_in ? launch<M64P>(a, s, plan_out) : launch<M64>(a, s, plan_out);
+  return plain_in ? launch<M32P>(a, s, plan_out) : launch<M32>(a, s, plan_out);
 #endif
 }
 

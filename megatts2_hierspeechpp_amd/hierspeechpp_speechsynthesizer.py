@@ -37,9 +37,12 @@ UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / ana
 # Activation1d placement.  The anti-aliased activation can run as the LDS prologue of the
 # following conv (no HBM round trip) or as its own HBM-bound launch in front of a plain conv.
 # On MI355X the fp32 MFMA shares the SIMD's fp32 datapath with the VALU, so prologue arithmetic
-# is paid in MFMA time; layers with more input channels than this run the activation unfused
-# (DESIGN.md §5 has the measurements behind the default).
-FUSE_ACT_MAX_CHANNELS = int(os.environ.get("HSP_FUSE_ACT_MAX_C", "64"))
+# is paid in MFMA time; layers with more input channels than this run the activation unfused.
+# With the wave-per-segment activation kernel (3.7-4.3 TB/s) and the plain low-channel convs at
+# two workgroups per CU the un-fused form wins at every width of the vocoder (DESIGN.md §5:
+# 104.4 / 102.5 / 101.3 ms per step for thresholds 64 / 32 / 0), so the default is 0; the fused
+# prologue stays available (and tested) behind this knob.
+FUSE_ACT_MAX_CHANNELS = int(os.environ.get("HSP_FUSE_ACT_MAX_C", "0"))
 
 
 class ResidualCouplingBlock_Transformer(nn.Module):

@@ -32,8 +32,15 @@ def test_golden(name, device):
 
 
 # ------------------------------------------------------------ (b) oracle, other sizes
-def _amp_case(device, C_, k, L, B, seed):
+def _amp_case(device, C_, k, L, B, seed, fuse_max_c=None):
     from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hs
+    if fuse_max_c is not None:   # Activation1d as the conv's LDS prologue (fused) or as its own launch
+        old, hs.FUSE_ACT_MAX_CHANNELS = hs.FUSE_ACT_MAX_CHANNELS, fuse_max_c
+        try:
+            return _amp_case(device, C_, k, L, B, seed)
+        finally:
+            hs.FUSE_ACT_MAX_CHANNELS = old
     from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import AMPBlock1
     from megatts2_hierspeechpp_amd.hip_layers import finalize
     from oracle import hsp_oracle as O
@@ -58,8 +65,38 @@ def _amp_case(device, C_, k, L, B, seed):
     (40, 5, 130, 3),     # channel count that is no multiple of the chunk / MFMA block
     (8, 3, 7, 2),        # shorter than the resampler support
 ])
-def test_amp_block_vs_oracle(C_, k, L, B, device):
-    _amp_case(device, C_, k, L, B, seed=100 + C_ + k)
+@pytest.mark.parametrize("fuse_max_c", [0, 1024], ids=["act-unfused", "act-fused"])
+def test_amp_block_vs_oracle(C_, k, L, B, fuse_max_c, device):
+    _amp_case(device, C_, k, L, B, seed=100 + C_ + k, fuse_max_c=fuse_max_c)
+
+
+@pytest.mark.parametrize("C_,L,B", [
+    (3, 4, 2),        # one float4: both replicate edges inside one vector
+    (5, 8, 1), (4, 12, 2), (2, 64, 1),
+    (3, 500, 2),      # one partial segment of the wave-per-segment kernel
+    (2, 504, 1),      # exactly one segment
+    (3, 508, 1),      # one segment + 4 outputs
+    (2, 800, 2),      # stage-1 length of the vocoder
+    (1, 1516, 2),     # three full segments + 4
+    (2, 4000, 1),
+    (3, 37, 2), (2, 1027, 1), (1, 2050, 1),   # L % 4 != 0: workgroup-tile kernel
+])
+def test_standalone_activation_vs_oracle(C_, L, B, device):
+    """hsp_act1d_snakebeta_f32 alone (alias_free_torch/act.py:23-28) against the oracle; lengths sit on the
+    segment / tile boundaries of both kernels behind the entry point."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from oracle import hsp_oracle as O
+    rng = np.random.default_rng(1000 + L)
+    x = torch.from_numpy(rng.standard_normal((B, C_, L)).astype(np.float32) * 1.5)
+    al = torch.from_numpy(rng.standard_normal(C_).astype(np.float32) * 0.5)
+    be = torch.from_numpy(rng.standard_normal(C_).astype(np.float32) * 0.5)
+    h = O.kaiser_sinc_filter12()
+    ref = O.act1d({"a.act.alpha": al, "a.act.beta": be}, "a", x).numpy()
+    filt = torch.cat([h.reshape(12), h.reshape(12)]).float().to(device)
+    ea = torch.exp(al).to(device)
+    binv = (1.0 / (torch.exp(be) + 1e-9)).to(device)
+    got = Fh.act1d(x.to(device), ea, binv, filt).cpu().numpy()
+    _close(got, ref, f"act1d C={C_} L={L}")
 
 
 @pytest.mark.parametrize("cin,cout,k,u,L", [(64, 32, 8, 4, 300), (48, 24, 11, 5, 77), (16, 8, 4, 2, 1000), (8, 4, 3, 3, 5)])
