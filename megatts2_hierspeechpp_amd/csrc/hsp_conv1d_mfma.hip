@@ -751,13 +751,17 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   if (a.debug & 256) return launch<M128>(a, s, plan_out);   // tuning: force a tile shape (results stay right)
   if (a.debug & 512) return launch<M256W8>(a, s, plan_out);
   if (a.debug & 1024) return launch<M64>(a, s, plan_out);
+  if (a.debug & 4096) return launch<S64>(a, s, plan_out);
+  if (a.debug & 8192) return launch<M64P>(a, s, plan_out);
+  if (a.debug & 16384) return launch<M256>(a, s, plan_out);
   if (a.M > 128) {
     // 256 x 128 tiles run one per CU, 128 x 128 tiles two per CU at half the work each: in units of
     // one 128 x 128 tile's MFMA time a CU spends 2 ceil(n256 / 256) against ceil(n128 / 256).
-    // The small tile wins whenever the large one leaves CUs idle (SourceNetwork, L = 400).
+    // The small tile wins whenever the large one leaves CUs idle (SourceNetwork, L = 400), and on
+    // ties too (a second resident workgroup hides the other's epilogue: 97.7 -> 96.4 ms per step).
     const int64_t nt = (a.ncols + 127) / 128;
     const int64_t n256 = (int64_t)((a.M + 255) / 256) * nt * a.B, n128 = (int64_t)((a.M + 127) / 128) * nt * a.B;
-    if ((n128 + 255) / 256 < 2 * ((n256 + 255) / 256)) return launch<M128>(a, s, plan_out);
+    if ((n128 + 255) / 256 <= 2 * ((n256 + 255) / 256) && !(a.debug & 32768)) return launch<M128>(a, s, plan_out);
     return launch<M256>(a, s, plan_out);
   }
   if (a.M > 64) return launch<M128>(a, s, plan_out);

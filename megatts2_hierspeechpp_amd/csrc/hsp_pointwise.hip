@@ -145,18 +145,50 @@ __global__ __launch_bounds__(ACT_THREADS) void act1d_kernel(const float* __restr
 // Every LDS access is contiguous across lanes (b64 / b128, lane stride = access width), so there
 // are no bank conflicts -- the workgroup-tile kernel above reads with lane strides of 2, 4 and 8
 // floats and is LDS-conflict bound at 1.7 TB/s.
-//   raw[j]  = x[clamp(p0 - 8 + j)]                       j in [0, 528)
+//   raw[j]  = x[clamp(p0 - 8 + j)]                       j in [0, 512)
 //   a2[j]   = a[clamp(2 p0 - 5 + j, 0, 2L - 1)]          j in [0, 1024): slot 4l of lane l is the
 //             first tap of outputs (p0 + 2l, p0 + 2l + 1) -> three b128 + one b64 read per pair.
 //   phase B: lane pair pi owns a[2q+1 .. 2q+4], q = p0 - 3 + 2 pi (odd(q), even(q+1), odd(q+1),
 //            even(q+2)): one b128 write at slot 4 pi; its inputs x[q-2 .. q+4] sit in four aligned
 //            b64 reads.  The x2 gain is folded into the taps (exact).
-constexpr int ACT2_SEG = 504;   // (SEG + 8) / 2 = 256 lane pairs = 4 full wave iterations
+constexpr int ACT2_SEG = 496;   // raw window = SEG + 16 = 512 floats = two float4 per lane
 constexpr int ACT2_WAVES = 4;
-constexpr int ACT2_RAW = 528;
+constexpr int ACT2_ITEMS = 4;   // consecutive segments per wave (software-pipelined loads)
+constexpr int ACT2_RAW = 512;
 constexpr int ACT2_A2 = 1040;
 
 __device__ __forceinline__ void act2_compiler_fence() { asm volatile("" ::: "memory"); }
+
+// raw window of work item w into registers (phase A loads): replicate padding; p0 - 8 and L are
+// multiples of 4, so a float4 lies wholly inside the row or wholly outside it.
+struct Act2Item {
+  int p0, n_out, c;
+  int64_t row_off;
+};
+
+__device__ __forceinline__ Act2Item act2_item(unsigned w, int nseg, int C, int L) {
+  const unsigned row = w / (unsigned)nseg;  // b * C + c
+  const int seg = (int)(w - row * (unsigned)nseg);
+  Act2Item it;
+  it.p0 = seg * ACT2_SEG;
+  it.n_out = min(ACT2_SEG, L - it.p0);  // multiple of 4
+  it.c = (int)(row % (unsigned)C);
+  it.row_off = (int64_t)row * L;
+  return it;
+}
+
+// Two unconditional float4 loads per lane (clamped address, so always legal and branch-free: a
+// load inside a divergent block gets an s_waitcnt vmcnt(0) right behind it and the round trips
+// serialise); the replicate padding is applied when the registers are written to LDS.
+__device__ __forceinline__ void act2_load(const float* __restrict__ x, const Act2Item& it, int L, int lane,
+                                          float4 (&rv)[2]) {
+  const float* xrow = x + it.row_off;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = it.p0 - 8 + 4 * (lane + 64 * k);
+    rv[k] = *reinterpret_cast<const float4*>(xrow + hsp_clampi(idx, 0, L - 4));
+  }
+}
 
 __global__ __launch_bounds__(64 * ACT2_WAVES) void act1d_seg_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                     int C, int L, const float* __restrict__ alpha_exp,
@@ -167,85 +199,83 @@ __global__ __launch_bounds__(64 * ACT2_WAVES) void act1d_seg_kernel(const float*
   __shared__ __attribute__((aligned(16))) float a2_all[ACT2_WAVES][ACT2_A2];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const unsigned w = blockIdx.x * ACT2_WAVES + wave;
-  if (w >= nwork) return;  // wave-uniform; the kernel has no workgroup barrier
-  const unsigned row = w / (unsigned)nseg;  // b * C + c
-  const int seg = (int)(w - row * (unsigned)nseg);
-  const int c = (int)(row % (unsigned)C);
-  const int p0 = seg * ACT2_SEG;
-  const int n_out = min(ACT2_SEG, L - p0);  // multiple of 4
-  const float* xrow = x + (int64_t)row * L;
-  float* yrow = y + (int64_t)row * L;
+  const unsigned w0 = (blockIdx.x * ACT2_WAVES + wave) * ACT2_ITEMS;
+  if (w0 >= nwork) return;  // wave-uniform; the kernel has no workgroup barrier
+  const unsigned w1 = min(w0 + ACT2_ITEMS, nwork);
   float* raw = raw_all[wave];
   float* a2 = a2_all[wave];
-  const float kf = alpha_exp[c] * 0.318309886183790672f, kb = 0.5f * beta_inv[c];
+  act_f32x2 hu[6], hd[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    hu[i] = act_f32x2{2.0f * filt[10 - 2 * i], 2.0f * filt[11 - 2 * i]};
+    hd[i] = act_f32x2{filt[12 + 2 * i], filt[13 + 2 * i]};
+  }
 
-  // ---- phase A: raw window, replicate padding.  p0 - 8 and L are multiples of 4, so a float4 lies
-  //      wholly inside the row or wholly outside it.
-  const int nv = min(ACT2_RAW / 4, (n_out + 24) >> 2);
-  float4 rv[3];
+  // A wave walks ACT2_ITEMS consecutive segments; the raw window of the next one is in flight
+  // (registers) while the current one is computed, so HBM latency is off the critical path.
+  Act2Item cur = act2_item(w0, nseg, C, L);
+  float4 rv[2];
+  act2_load(x, cur, L, lane, rv);
+  for (unsigned w = w0; w < w1; ++w) {
+    const int p0 = cur.p0, n_out = cur.n_out;
+    float* yrow = y + cur.row_off;
+    const float kf = alpha_exp[cur.c] * 0.318309886183790672f, kb = 0.5f * beta_inv[cur.c];
+    // ---- phase A: registers -> LDS, then start the next item's loads
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {  // 132 float4 at most; all loads in flight before the first LDS write
-    const int v = lane + 64 * it;
-    const int idx = p0 - 8 + 4 * v;
-    if (v < nv) {
-      float4 t = *reinterpret_cast<const float4*>(xrow + hsp_clampi(idx, 0, L - 4));
-      if (idx < 0) t = make_float4(t.x, t.x, t.x, t.x);
-      if (idx >= L) t = make_float4(t.w, t.w, t.w, t.w);
-      rv[it] = t;
+    for (int k = 0; k < 2; ++k) {
+      const int v = lane + 64 * k;
+      const int idx = p0 - 8 + 4 * v;
+      float4 t = rv[k];
+      t = idx < 0 ? make_float4(t.x, t.x, t.x, t.x) : t;    // clamped address was 0:     x[0]
+      t = idx >= L ? make_float4(t.w, t.w, t.w, t.w) : t;   // clamped address was L - 4: x[L-1]
+      *reinterpret_cast<float4*>(raw + 4 * v) = t;
     }
-  }
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const int v = lane + 64 * it;
-    if (v < nv) *reinterpret_cast<float4*>(raw + 4 * v) = rv[it];
-  }
-  act2_compiler_fence();
-
-  // ---- phase B
-  act_f32x2 hu[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) hu[i] = act_f32x2{2.0f * filt[10 - 2 * i], 2.0f * filt[11 - 2 * i]};
-  const int npairs = (2 * n_out + 13) >> 2;  // slots [0, 2 n_out + 10)
-#pragma unroll 2
-  for (int pi = lane; pi < npairs; pi += 64) {
-    const act_f32x2* rp = reinterpret_cast<const act_f32x2*>(raw + 2 * pi + 2);
-    const act_f32x2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-    const float xv[7] = {r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};  // x[q-2 .. q+4]
-    act_f32x2 u0 = {0.0f, 0.0f}, u1 = {0.0f, 0.0f};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      u0 = __builtin_elementwise_fma(act_f32x2{xv[i], xv[i]}, hu[i], u0);          // a[2q+1], a[2q+2]
-      u1 = __builtin_elementwise_fma(act_f32x2{xv[i + 1], xv[i + 1]}, hu[i], u1);  // a[2q+3], a[2q+4]
+    if (w + 1 < w1) {
+      cur = act2_item(w + 1, nseg, C, L);
+      act2_load(x, cur, L, lane, rv);
     }
-    *reinterpret_cast<float4*>(a2 + 4 * pi) = make_float4(hsp_snake_hw(u0.x, kf, kb), hsp_snake_hw(u0.y, kf, kb),
-                                                          hsp_snake_hw(u1.x, kf, kb), hsp_snake_hw(u1.y, kf, kb));
-  }
-  act2_compiler_fence();
-  // replicate padding of the 2x-rate signal: a[-5 .. -1] = a[0], a[2L .. 2L+4] = a[2L-1]
-  if (p0 == 0 || p0 + n_out == L) {
-    if (p0 == 0 && lane < 5) a2[lane] = a2[5];
-    if (p0 + n_out == L && lane >= 8 && lane < 13) a2[2 * n_out + lane - 3] = a2[2 * n_out + 4];
     act2_compiler_fence();
-  }
 
-  // ---- phase C: y[p0 + s] = sum_k hd[k] * a2[2 s + k], two outputs per lane
-  act_f32x2 hd[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) hd[k] = act_f32x2{filt[12 + 2 * k], filt[13 + 2 * k]};
+    // ---- phase B
+    const int npairs = (2 * n_out + 13) >> 2;  // slots [0, 2 n_out + 10)
 #pragma unroll 2
-  for (int l2 = lane; 2 * l2 < n_out; l2 += 64) {
-    const float4* ap = reinterpret_cast<const float4*>(a2 + 4 * l2);
-    const float4 w0 = ap[0], w1 = ap[1], w2 = ap[2];
-    const act_f32x2 w3 = *reinterpret_cast<const act_f32x2*>(a2 + 4 * l2 + 12);
-    const act_f32x2 aw[7] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}, {w2.x, w2.y}, {w2.z, w2.w}, w3};
-    act_f32x2 s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
+    for (int pi = lane; pi < npairs; pi += 64) {
+      const act_f32x2* rp = reinterpret_cast<const act_f32x2*>(raw + 2 * pi + 2);
+      const act_f32x2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      const float xv[7] = {r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};  // x[q-2 .. q+4]
+      act_f32x2 u0 = {0.0f, 0.0f}, u1 = {0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      s0 = __builtin_elementwise_fma(aw[k], hd[k], s0);
-      s1 = __builtin_elementwise_fma(aw[k + 1], hd[k], s1);
+      for (int i = 0; i < 6; ++i) {
+        u0 = __builtin_elementwise_fma(act_f32x2{xv[i], xv[i]}, hu[i], u0);          // a[2q+1], a[2q+2]
+        u1 = __builtin_elementwise_fma(act_f32x2{xv[i + 1], xv[i + 1]}, hu[i], u1);  // a[2q+3], a[2q+4]
+      }
+      *reinterpret_cast<float4*>(a2 + 4 * pi) = make_float4(hsp_snake_hw(u0.x, kf, kb), hsp_snake_hw(u0.y, kf, kb),
+                                                            hsp_snake_hw(u1.x, kf, kb), hsp_snake_hw(u1.y, kf, kb));
     }
-    *reinterpret_cast<float2*>(yrow + p0 + 2 * l2) = make_float2(s0.x + s0.y, s1.x + s1.y);
+    act2_compiler_fence();
+    // replicate padding of the 2x-rate signal: a[-5 .. -1] = a[0], a[2L .. 2L+4] = a[2L-1]
+    if (p0 == 0 || p0 + n_out == L) {
+      if (p0 == 0 && lane < 5) a2[lane] = a2[5];
+      if (p0 + n_out == L && lane >= 8 && lane < 13) a2[2 * n_out + lane - 3] = a2[2 * n_out + 4];
+      act2_compiler_fence();
+    }
+
+    // ---- phase C: y[p0 + s] = sum_k hd[k] * a2[2 s + k], two outputs per lane
+#pragma unroll 2
+    for (int l2 = lane; 2 * l2 < n_out; l2 += 64) {
+      const float4* ap = reinterpret_cast<const float4*>(a2 + 4 * l2);
+      const float4 q0 = ap[0], q1 = ap[1], q2 = ap[2];
+      const act_f32x2 q3 = *reinterpret_cast<const act_f32x2*>(a2 + 4 * l2 + 12);
+      const act_f32x2 aw[7] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}, q3};
+      act_f32x2 s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        s0 = __builtin_elementwise_fma(aw[k], hd[k], s0);
+        s1 = __builtin_elementwise_fma(aw[k + 1], hd[k], s1);
+      }
+      *reinterpret_cast<float2*>(yrow + p0 + 2 * l2) = make_float2(s0.x + s0.y, s1.x + s1.y);
+    }
+    act2_compiler_fence();  // raw / a2 are rewritten by the next item
   }
 }
 
@@ -486,8 +516,8 @@ extern "C" int hsp_act1d_snakebeta_f32(const float* x, float* y, int32_t B, int3
   if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
     const int nseg = (L + ACT2_SEG - 1) / ACT2_SEG;
     const int64_t nwork = (int64_t)nseg * B * C;
-    const int64_t blocks = (nwork + ACT2_WAVES - 1) / ACT2_WAVES;
-    if (nwork > 0x7fffffff) return HSP_EINVAL;
+    const int64_t blocks = (nwork + ACT2_WAVES * ACT2_ITEMS - 1) / (ACT2_WAVES * ACT2_ITEMS);
+    if (nwork > 0x7fffffff - ACT2_WAVES * ACT2_ITEMS) return HSP_EINVAL;
     hipLaunchKernelGGL(act1d_seg_kernel, dim3((unsigned)blocks), dim3(64 * ACT2_WAVES), 0, HSP_STREAM, x, y, C, L,
                        alpha_exp, beta_inv, filt, nseg, (unsigned)nwork);
     return (int)hipGetLastError();

@@ -13,6 +13,7 @@ job can ship them with a single RCCL broadcast.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -26,7 +27,7 @@ from .synth import kaiser_sinc_filter12
 # Optional measurement hook (bench.py): called as hook(kind, flops, bytes, ev_start, ev_end, args)
 # with torch.cuda.Events recorded around the launch on the launch stream.
 LAUNCH_HOOK = None
-DEBUG_FLAGS = 0  # hsp_conv1d_args.debug for every conv launch (kernel tuning only)
+DEBUG_FLAGS = int(os.environ.get("HSP_CONV_DEBUG", "0"))  # hsp_conv1d_args.debug for every conv launch (kernel tuning only)
 
 
 _ZEROS = {}

@@ -73,12 +73,12 @@ def test_amp_block_vs_oracle(C_, k, L, B, fuse_max_c, device):
 @pytest.mark.parametrize("C_,L,B", [
     (3, 4, 2),        # one float4: both replicate edges inside one vector
     (5, 8, 1), (4, 12, 2), (2, 64, 1),
-    (3, 500, 2),      # one partial segment of the wave-per-segment kernel
-    (2, 504, 1),      # exactly one segment
-    (3, 508, 1),      # one segment + 4 outputs
+    (3, 492, 2),      # one partial segment of the wave-per-segment kernel
+    (2, 496, 1),      # exactly one segment
+    (3, 500, 1),      # one segment + 4 outputs
     (2, 800, 2),      # stage-1 length of the vocoder
-    (1, 1516, 2),     # three full segments + 4
-    (2, 4000, 1),
+    (1, 1492, 2),     # three full segments + 4
+    (2, 4000, 3),     # 9 segments per row: waves walk several rows' segments (4 consecutive items each)
     (3, 37, 2), (2, 1027, 1), (1, 2050, 1),   # L % 4 != 0: workgroup-tile kernel
 ])
 def test_standalone_activation_vs_oracle(C_, L, B, device):
