@@ -178,7 +178,8 @@ def main():
                       "are excluded: %d launches, %.2f ms per step)" % (len(tg), sum(m for _, _, m in tg)),
             "bound": "mfma", "achieved": ach,
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate passes, each scaled by the factor "
+                            "calibrated on a known-bytes launch of this kernel: profiles/r01_traffic.json)",
             "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
             "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
             "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,

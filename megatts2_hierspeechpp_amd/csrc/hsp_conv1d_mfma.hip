@@ -39,7 +39,6 @@ int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);
 
 namespace {
 
-
 template <int WM, int WN, int TM, int TN, int NPW_, int MINW_>
 struct Cfg {
   static constexpr int NCW = WM * WN;              // consumer waves (4, or 8 = two per SIMD)
@@ -719,7 +718,6 @@ int validate(const hsp_conv1d_args& a) {
 
 // tile shapes <WM, WN, TM, TN, producer waves, min waves per SIMD>
 using M256 = Cfg<2, 2, 4, 2, 4, 2>;    // 256 x 128, one workgroup per CU
-using M256W8 = Cfg<4, 2, 2, 2, 4, 3>;  // 256 x 128, eight consumer waves (two per SIMD)
 using M128 = Cfg<2, 2, 2, 2, 4, 4>;    // 128 x 128, two workgroups per CU
 using M64 = Cfg<1, 4, 2, 2, 8, 3>;     //  64 x 256
 using M32 = Cfg<1, 4, 1, 4, 8, 3>;     //  32 x 512
@@ -749,7 +747,6 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     return launch<S32>(a, s, plan_out);
   }
   if (a.debug & 256) return launch<M128>(a, s, plan_out);   // tuning: force a tile shape (results stay right)
-  if (a.debug & 512) return launch<M256W8>(a, s, plan_out);
   if (a.debug & 1024) return launch<M64>(a, s, plan_out);
   if (a.debug & 4096) return launch<S64>(a, s, plan_out);
   if (a.debug & 8192) return launch<M64P>(a, s, plan_out);
