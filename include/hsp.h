@@ -284,6 +284,23 @@ int hsp_zero_below_f32(const float* x, float thr, float* y, int64_t n, void* str
 int hsp_peak_int16(const float* x, int64_t x_bs, const int64_t* lengths, float gain, int16_t* out, int64_t o_bs,
                    int32_t B, int64_t n, void* stream);
 
+/* ------------------------------------------------ prompt front-end */
+/* torchaudio MelSpectrogram as wrapped by MelSpectrogramFixed (Mels_preprocess.py:8-18; built with the
+ * kwargs of inference_plm.py:204-213, applied at :134,150).  Three steps: these two kernels around one
+ * hsp_conv1d_mfma_f32 launch (K = 1, Cin = n_fft) against the host-built DFT matrix.
+ * frames[b][n][t] = window[n] * x[b][reflect(t * hop + n - n_fft / 2)], t < T = 1 + L / hop
+ *   (torch.stft center=True, pad_mode="reflect": index i < 0 -> -i, i >= L -> 2 (L - 1) - i; needs
+ *   L > n_fft / 2); x [B, L] contiguous, frames [B, n_fft, f_ld] with row pitch f_ld >= T. */
+int hsp_stft_frames_f32(const float* x, const float* window, float* frames, int32_t B, int32_t L, int32_t n_fft,
+                        int32_t hop, int32_t T, int32_t f_ld, void* stream);
+/* out[b][m][t] = log(sum_f fb[f][m] * (re[b][f][t]^2 + im[b][f][t]^2) + eps), t < T_out :
+ *   Spectrogram(power=2) -> MelScale -> log(. + 0.001)[..., :-1].  spec[b] holds rows 0 .. n_freqs-1 (real)
+ *   and n_freqs .. 2 n_freqs - 1 (imaginary) with row pitch s_ld and batch stride s_bs; fb [n_freqs, n_mels]
+ *   row-major; filter m is non-zero only on bins [f_lo[m], f_hi[m]); out [B, n_mels, T_out] contiguous. */
+int hsp_power_mel_log_f32(const float* spec, int64_t s_bs, int32_t s_ld, const float* fb, const int32_t* f_lo,
+                          const int32_t* f_hi, float* out, int32_t B, int32_t n_freqs, int32_t n_mels,
+                          int32_t T_out, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

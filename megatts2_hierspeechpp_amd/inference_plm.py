@@ -58,6 +58,34 @@ def peak_int16(audio, lengths=None, gain: float = 0.999):
     return out
 
 
+def prompt_mels(mel_fn, audio):
+    """The two prompt mels of inference_plm.py:130-150 (denoise_ratio = 0 branch): ``src_mel_ttv`` from the prompt
+    zero-padded to the next multiple of 1600 samples (always at least one sample of padding, :131-134), and
+    ``src_mel`` [2, 80, T] from the un-padded prompt stacked twice (:144,150).  ``audio`` [1, n] fp32 on the GPU;
+    ``mel_fn`` a finalized Mels_preprocess.MelSpectrogramFixed."""
+    n = audio.shape[-1]
+    padded = torch.zeros(audio.shape[0], (n // 1600 + 1) * 1600, dtype=audio.dtype, device=audio.device)
+    padded[:, :n].copy_(audio)
+    src_mel_ttv = mel_fn(padded)
+    src_mel = mel_fn(audio)
+    src_mel = src_mel.repeat(2, 1, 1) if src_mel.shape[0] == 1 else torch.cat([src_mel, src_mel], 0)
+    return src_mel_ttv, src_mel
+
+
+def write_wav(path, sample_rate: int, pcm):
+    """scipy.io.wavfile.write(path, rate, int16 array) of inference_plm.py:195-200: 16-bit mono PCM RIFF."""
+    import wave
+    import numpy as np
+    a = pcm.detach().cpu().numpy() if isinstance(pcm, torch.Tensor) else np.asarray(pcm)
+    if a.dtype != np.int16 or a.ndim != 1:
+        raise ValueError("write_wav takes a 1-D int16 array (one utterance)")
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(int(sample_rate))
+        f.writeframes(a.astype("<i2").tobytes())
+
+
 @torch.no_grad()
 def tts(models: TtsModels, text, text_length, tone, language, src_mel_ttv, src_mel_ttv_length, src_mel, src_length2,
         noise_scale_vc: float = 0.333, denoise_ratio: float = 0.0, output_sr: int = 16000, dur=None, noise=None,

@@ -401,3 +401,58 @@ def test_fused_layernorm_gemm_vs_torch(device):
         _close(got.numpy(), torch.relu(ref).transpose(1, 2).numpy(), f"ln+gemm {cin}->{cout} N={N}")
     with pytest.raises(L.HspError):
         lin(torch.randn(1, 192, 18).to(device))                     # 18 columns: rows are not 16-B addressable
+
+
+# ------------------------------------------------------------ prompt mel
+@pytest.fixture(scope="module")
+def mel_fn(device):
+    from megatts2_hierspeechpp_amd.Mels_preprocess import MelSpectrogramFixed
+    return MelSpectrogramFixed(sample_rate=16000, n_fft=1280, win_length=1280, hop_length=320, f_min=0, f_max=8000,
+                               n_mels=80, window_fn=torch.hann_window).finalize(device)
+
+
+def _prompt_audio(B, L, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(L) / 16000.0
+    f0 = rng.uniform(90, 300, (B, 1))
+    voiced = sum(np.sin(2 * np.pi * f0 * h * t) / h for h in range(1, 12))   # harmonic stack + noise floor
+    env = 0.5 + 0.5 * np.sin(2 * np.pi * 2.5 * t)
+    return (0.15 * voiced * env + 0.02 * rng.standard_normal((B, L))).astype(np.float32)
+
+
+@pytest.mark.parametrize("L,B", [
+    (16000, 2), (48000, 1),   # 1 s and 3 s prompts
+    (4801, 1),                # length that is no multiple of the hop
+    (1000, 3),                # shorter than one window: both reflections inside every frame
+    (641, 1),                 # shortest length torch.stft accepts (L > n_fft / 2)
+    (81920, 2),               # 256 frames: several column tiles of the DFT GEMM
+])
+def test_mel_spectrogram_vs_oracle(L, B, mel_fn, device):
+    """MelSpectrogramFixed (Mels_preprocess.py:8-18) through the C ABI against the oracle; log-mel tolerance
+    1e-4 * max|ref| like every other tensor of the path."""
+    from oracle import hsp_oracle as O
+    x = _prompt_audio(B, L, 7 + L)
+    got = mel_fn(torch.from_numpy(x).to(device)).cpu().numpy()
+    ref = O.mel_spectrogram_fixed(torch.from_numpy(x)).numpy()
+    _close(got, ref, f"mel L={L}")
+
+
+def test_prompt_mels_and_abi_checks(mel_fn, device):
+    """inference_plm.py:130-150: padded / un-padded prompt mels; argument checks of the two entry points."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.inference_plm import prompt_mels
+    from oracle import hsp_oracle as O
+    x = _prompt_audio(1, 37777, 3)
+    mel_ttv, mel = prompt_mels(mel_fn, torch.from_numpy(x).to(device))
+    n_pad = (37777 // 1600 + 1) * 1600
+    xp = np.zeros((1, n_pad), np.float32)
+    xp[:, :37777] = x
+    _close(mel_ttv.cpu().numpy(), O.mel_spectrogram_fixed(torch.from_numpy(xp)).numpy(), "src_mel_ttv")
+    ref = O.mel_spectrogram_fixed(torch.from_numpy(x)).numpy()
+    assert mel.shape == (2, 80, 37777 // 320)
+    _close(mel.cpu().numpy(), np.concatenate([ref, ref], 0), "src_mel")
+    with pytest.raises(L.HspError):
+        mel_fn(torch.zeros(1, 640, device=device))     # reflect padding impossible
+    lib = L.lib()
+    assert lib.hsp_stft_frames_f32(None, None, None, 1, 16000, 1280, 320, 51, 52, None) == L.EINVAL
+    assert lib.hsp_power_mel_log_f32(None, 0, 0, None, None, None, None, 1, 641, 80, 50, 0.001, None) == L.EINVAL

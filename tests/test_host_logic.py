@@ -164,3 +164,40 @@ def test_ctypes_structs_match_the_header(tmp_path):
     want = [ctypes.sizeof(_lib.Conv1dArgs)] + [getattr(_lib.Conv1dArgs, f).offset for f in fields_c]
     want += [ctypes.sizeof(_lib.MhaArgs)] + [getattr(_lib.MhaArgs, f).offset for f in fields_m]
     assert vals == want
+
+
+def test_write_wav_round_trip(tmp_path):
+    """inference_plm.py:195-200 writes int16 mono PCM with scipy.io.wavfile.write; the mirror's writer must
+    produce a file scipy reads back bit-exactly."""
+    from scipy.io import wavfile
+    from megatts2_hierspeechpp_amd.inference_plm import write_wav
+    pcm = (np.random.default_rng(0).integers(-32768, 32767, 4801)).astype(np.int16)
+    for sr in (16000, 24000, 48000):
+        p = tmp_path / f"a{sr}.wav"
+        write_wav(p, sr, torch.from_numpy(pcm))
+        rate, back = wavfile.read(p)
+        assert rate == sr and back.dtype == np.int16 and np.array_equal(back, pcm)
+    with pytest.raises(ValueError):
+        write_wav(tmp_path / "bad.wav", 16000, pcm.astype(np.float32))
+
+
+def test_mel_front_end_host_side():
+    """MelSpectrogramFixed mirror: constructor surface of inference_plm.py:204-213, DFT basis rows, refusal of
+    CPU input / unsupported options (no fallback)."""
+    from megatts2_hierspeechpp_amd import _lib
+    from megatts2_hierspeechpp_amd.Mels_preprocess import MelSpectrogramFixed, melscale_fbanks_htk
+    m = MelSpectrogramFixed(sample_rate=16000, n_fft=1280, win_length=1280, hop_length=320, f_min=0, f_max=8000,
+                            n_mels=80, window_fn=torch.hann_window)
+    w = m.dft.weight.detach().numpy().reshape(1282, 1280)
+    n = np.arange(1280)
+    assert np.abs(w[3] - np.cos(2 * np.pi * 3 * n / 1280)).max() < 1e-6
+    assert np.abs(w[641 + 7] + np.sin(2 * np.pi * 7 * n / 1280)).max() < 1e-6
+    assert np.allclose(w[0], 1.0) and np.allclose(w[641], 0.0)
+    fb = melscale_fbanks_htk(641, 0.0, 8000.0, 80, 16000)
+    assert fb.shape == (641, 80) and (fb >= 0).all() and ((fb > 0).sum(1) <= 2).all()   # triangles overlap pairwise
+    with pytest.raises(_lib.HspError):
+        m(torch.zeros(1, 16000))                       # not finalized / CPU tensor: refuse
+    with pytest.raises(_lib.HspError):
+        MelSpectrogramFixed(n_fft=1280, win_length=640)
+    with pytest.raises(_lib.HspError):
+        MelSpectrogramFixed(n_fft=1280, power=1.0)

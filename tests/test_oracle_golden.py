@@ -47,3 +47,38 @@ def test_kaiser_filter_matches_reference_buffer():
     want = [0.0020289647, 0.0093894657, -0.0255434588, -0.0576573834, 0.1285725832, 0.4432097971]
     assert np.allclose(h[:6], want, atol=2e-7) and np.allclose(h[6:], h[:6][::-1], atol=1e-8)
     assert abs(h.sum() - 1.0) < 1e-6
+
+
+# ---------------------------------------------------------------- prompt mel
+def _mel_float64(x, n_fft=1280, hop=320, sr=16000, f_min=0.0, f_max=8000.0, n_mels=80):
+    """Independent float64 numpy restatement of torchaudio's MelSpectrogram + the wrapper's log / crop
+    (Mels_preprocess.py:8-18): explicit reflect padding, explicit frames, numpy rfft, closed-form Hann and
+    HTK triangles.  torchaudio is not in the image and the reference holds no vector for it, so this is the pin."""
+    xp = np.pad(x.astype(np.float64), ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+    T = 1 + x.shape[1] // hop
+    n = np.arange(n_fft)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * n / n_fft)
+    fr = np.stack([xp[:, t * hop:t * hop + n_fft] * w for t in range(T)], axis=1)
+    X = np.fft.rfft(fr, axis=-1)
+    P = X.real ** 2 + X.imag ** 2
+    allf = np.linspace(0, sr // 2, n_fft // 2 + 1)
+    mel = lambda f: 2595 * np.log10(1 + f / 700)
+    fp = 700 * (10 ** (np.linspace(mel(f_min), mel(f_max), n_mels + 2) / 2595) - 1)
+    fd = fp[1:] - fp[:-1]
+    sl = fp[None, :] - allf[:, None]
+    fb = np.maximum(0, np.minimum(-sl[:, :-2] / fd[:-1], sl[:, 2:] / fd[1:]))
+    return np.log(P @ fb + 1e-3).transpose(0, 2, 1)[..., :-1], fb
+
+
+@pytest.mark.parametrize("L,B", [(16000, 2), (4801, 1), (1000, 3), (641, 1), (24000, 1)])
+def test_mel_oracle_matches_float64_restatement(L, B):
+    from oracle import hsp_oracle as O
+    rng = np.random.default_rng(L)
+    t = np.arange(L) / 16000.0
+    x = (0.1 * rng.standard_normal((B, L)) + 0.3 * np.sin(2 * np.pi * 220.0 * t) * np.linspace(0, 1, L)).astype(np.float32)
+    got = O.mel_spectrogram_fixed(torch.from_numpy(x)).numpy()
+    ref, fb = _mel_float64(x)
+    assert got.shape == ref.shape == (B, 80, L // 320)
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    fbo = O.melscale_fbanks_htk(641, 0.0, 8000.0, 80, 16000).numpy()
+    assert np.abs(fbo - fb).max() < 1e-4 and (fbo >= 0).all() and (fbo.sum(0) > 0).all()
