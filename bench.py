@@ -142,10 +142,14 @@ def main():
                 kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else "hsp_conv1d_mfma_f32/tokgemm"
             rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
 
+        from megatts2_hierspeechpp_amd import functional as Fh
+        act_rec = []
+        Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
         hip_layers.LAUNCH_HOOK = hook
         eager_step()
         torch.cuda.synchronize()
         hip_layers.LAUNCH_HOOK = None
+        Fh.ACT_HOOK = None
         hss.AMP_STREAMS, hss.FRONT_SPLITS = saved
         mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
         tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32/tokgemm"]
@@ -187,6 +191,18 @@ def main():
             "share_of_step_time_single_stream": tot_ms / ms_per_step,
             "timing": "one extra step, launches serialised on one stream, event pair per launch",
         }
+        if act_rec:
+            # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
+            a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)
+            a_b = sum(nb for nb, _, _ in act_rec)
+            a_gbs = a_b / (a_ms * 1e-3) / 1e9
+            result["roofline_activation"] = {
+                "kernel": "act1d_seg_kernel (hsp_act1d_snakebeta_f32)", "bound": "hbm", "achieved": a_gbs,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_gbs / HBM_PEAK_GBS, "launches_per_step": len(act_rec),
+                "kernel_ms_per_step": a_ms, "algorithmic_mb_per_step": a_b / 1e6,
+                "algorithmic_bytes": "one fp32 read + one fp32 write per element", "traffic": None,
+                "timing": "same pass as `roofline`",
+            }
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

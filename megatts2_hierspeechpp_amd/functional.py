@@ -28,12 +28,22 @@ def sequence_mask(length: torch.Tensor, max_length: int) -> torch.Tensor:
     return mask
 
 
+ACT_HOOK = None  # measurement hook (bench.py): hook(algorithmic_bytes, ev_start, ev_end) around every stand-alone activation
+
+
 def act1d(x, ea, binv, filt, out=None):
     x = _c(x)
     B, Cc, T = x.shape
     out = _new_like(x) if out is None else out
+    hook = ACT_HOOK
+    if hook is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.lib().hsp_act1d_snakebeta_f32(L.fptr(x), L.fptr(out), B, Cc, T, L.fptr(ea), L.fptr(binv), L.fptr(filt),
                                             L.stream_ptr()), "hsp_act1d_snakebeta_f32")
+    if hook is not None:
+        e1.record()
+        hook(8 * B * Cc * T, e0, e1)   # one fp32 read + one fp32 write per element
     return out
 
 
