@@ -213,9 +213,23 @@ __global__ __launch_bounds__(64 * ACT2_WAVES) void act1d_seg_kernel(const float*
 
   // A wave walks ACT2_ITEMS consecutive segments; the raw window of the next one is in flight
   // (registers) while the current one is computed, so HBM latency is off the critical path.
+  // The outputs of an item stay in registers and are stored one iteration later, BEFORE the next
+  // prefetch is issued: vmcnt retires in order, so the wait for a prefetch would otherwise also wait
+  // for the stores issued just before it (a full write round trip per item).
   Act2Item cur = act2_item(w0, nseg, C, L);
   float4 rv[2];
   act2_load(x, cur, L, lane, rv);
+  constexpr int NC = (ACT2_SEG / 2 + 63) / 64;  // phase-C iterations of a full segment
+  float2 yo[NC];
+  float* yprev = nullptr;
+  int nprev = 0;
+  auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+      const int l2 = lane + 64 * it;
+      if (2 * l2 < nprev) *reinterpret_cast<float2*>(yprev + 2 * l2) = yo[it];
+    }
+  };
   for (unsigned w = w0; w < w1; ++w) {
     const int p0 = cur.p0, n_out = cur.n_out;
     float* yrow = y + cur.row_off;
@@ -230,6 +244,8 @@ __global__ __launch_bounds__(64 * ACT2_WAVES) void act1d_seg_kernel(const float*
       t = idx >= L ? make_float4(t.w, t.w, t.w, t.w) : t;   // clamped address was L - 4: x[L-1]
       *reinterpret_cast<float4*>(raw + 4 * v) = t;
     }
+    act2_compiler_fence();  // keeps the deferred stores behind the wait for rv (the scheduler hoists them into the latch otherwise)
+    if (yprev) flush();     // previous item's outputs: ahead of the prefetch in vmcnt order
     if (w + 1 < w1) {
       cur = act2_item(w + 1, nseg, C, L);
       act2_load(x, cur, L, lane, rv);
@@ -261,8 +277,10 @@ __global__ __launch_bounds__(64 * ACT2_WAVES) void act1d_seg_kernel(const float*
     }
 
     // ---- phase C: y[p0 + s] = sum_k hd[k] * a2[2 s + k], two outputs per lane
-#pragma unroll 2
-    for (int l2 = lane; 2 * l2 < n_out; l2 += 64) {
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+      const int l2 = lane + 64 * it;
+      if (2 * l2 >= n_out) continue;
       const float4* ap = reinterpret_cast<const float4*>(a2 + 4 * l2);
       const float4 q0 = ap[0], q1 = ap[1], q2 = ap[2];
       const act_f32x2 q3 = *reinterpret_cast<const act_f32x2*>(a2 + 4 * l2 + 12);
@@ -273,10 +291,13 @@ __global__ __launch_bounds__(64 * ACT2_WAVES) void act1d_seg_kernel(const float*
         s0 = __builtin_elementwise_fma(aw[k], hd[k], s0);
         s1 = __builtin_elementwise_fma(aw[k + 1], hd[k], s1);
       }
-      *reinterpret_cast<float2*>(yrow + p0 + 2 * l2) = make_float2(s0.x + s0.y, s1.x + s1.y);
+      yo[it] = make_float2(s0.x + s0.y, s1.x + s1.y);
     }
+    yprev = yrow + p0;
+    nprev = n_out;
     act2_compiler_fence();  // raw / a2 are rewritten by the next item
   }
+  flush();
 }
 
 __global__ void snake_consts_kernel(const float* al, const float* bl, float* ea, float* binv, int C) {
