@@ -203,6 +203,13 @@ def main():
                 "algorithmic_bytes": "one fp32 read + one fp32 write per element", "traffic": None,
                 "timing": "same pass as `roofline`",
             }
+            try:  # PMC bytes of the same kernel (profiles/r01_traffic.json; FETCH_SIZE doubled as the guide prescribes)
+                if tj.get("batch_per_gpu") == B and tj.get("frames") == T:
+                    result["roofline_activation"]["traffic"] = tj["act1d_seg_bytes_per_step"] / len(act_rec)
+                    result["roofline_activation"]["traffic_unit"] = "HBM bytes per launch (PMC, profiles/r01_traffic.json)"
+                    result["roofline_activation"]["algorithmic_bytes_per_launch"] = a_b / len(act_rec)
+            except (NameError, KeyError):
+                pass
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

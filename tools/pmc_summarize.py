@@ -63,5 +63,10 @@ res = {
     "conv1d_mfma_bytes_per_step_uncorrected": (conv["FETCH_SIZE_KB"] + conv["WRITE_SIZE_KB"]) * 1024 / steps,
     "conv1d_mfma_launches_per_step": conv["launches"] / steps,
 }
+act = out.get("act1d_seg_kernel")
+if act:
+    # 16-B/lane streaming global_load: FETCH_SIZE reports exactly 1/2 (MI355X_MICROARCH.md, HBM); stores read exactly
+    res["act1d_seg_bytes_per_step"] = (2.0 * act["FETCH_SIZE_KB"] + act["WRITE_SIZE_KB"]) * 1024 / steps
+    res["act1d_seg_launches_per_step"] = act["launches"] / steps
 json.dump(res, open(dst, "w"), indent=1)
 print({k: res[k] for k in ("fetch_factor", "write_factor", "conv1d_mfma_bytes_per_step", "conv1d_mfma_launches_per_step")})
