@@ -124,3 +124,24 @@ def tts(models: TtsModels, text, text_length, tone, language, src_mel_ttv, src_m
             n_valid = n_valid * output_sr // 16000
     wav = peak_int16(audio, n_valid)
     return (wav, audio) if return_float else wav
+
+
+@torch.no_grad()
+def tts_from_prompt(models: TtsModels, mel_fn, text, tone, language, prompt_audio, output_path=None,
+                    noise_scale_vc: float = 0.333, output_sr: int = 16000, dur=None, noise=None):
+    """inference_plm.py:tts :126-201 from the prompt WAVEFORM on (denoise_ratio = 0 branch): prompt mels
+    (:130-150, `prompt_mels`), text -> w2v / f0 -> waveform (`tts`), optional 16-bit WAV (:195-200).
+    text / tone / language int64 [1, N] on the GPU; prompt_audio fp32 [1, n] at 16 kHz on the GPU;
+    ``mel_fn`` a finalized Mels_preprocess.MelSpectrogramFixed.  Returns int16 [n_out]."""
+    src_mel_ttv, src_mel = prompt_mels(mel_fn, prompt_audio)
+    dev = prompt_audio.device
+    B = text.shape[0]
+    assert B == 1 and prompt_audio.shape[0] == 1, "the reference harness synthesises one utterance per call"
+    text_length = torch.full((B,), text.shape[1], dtype=torch.int64, device=dev)
+    ttv_len = torch.full((B,), src_mel_ttv.shape[2], dtype=torch.int64, device=dev)
+    src_length2 = torch.full((2 * B,), src_mel.shape[2], dtype=torch.int64, device=dev)
+    wav = tts(models, text, text_length, tone, language, src_mel_ttv, ttv_len, src_mel, src_length2,
+              noise_scale_vc=noise_scale_vc, denoise_ratio=0.0, output_sr=output_sr, dur=dur, noise=noise)[0]
+    if output_path is not None:
+        write_wav(output_path, output_sr if output_sr in (24000, 48000) else 16000, wav)
+    return wav

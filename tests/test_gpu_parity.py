@@ -379,6 +379,37 @@ def test_tts_batch_rows_match_single_runs(device):
         assert int((w1[0].int() - wav[b].int()).abs().max()) <= 3
 
 
+def test_tts_from_prompt_waveform(mel_fn, device, tmp_path):
+    """Wav in -> wav out (inference_plm.py:126-201 on tensors): prompt waveform -> HIP mels -> tts -> int16 file.
+    Must equal `tts` fed with the same mels, be deterministic, and the file must read back bit-exactly."""
+    from scipy.io import wavfile
+    from megatts2_hierspeechpp_amd import inference_plm as IP, synth
+    from oracle.hsp_oracle import default_config
+    models = IP.TtsModels(default_config(), H.TTV_MODEL)
+    models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 7)) for k, v in models.state_dict().items()})
+    models.finalize(device)
+    r = np.random.default_rng(5)
+    N = 7
+    ids = torch.from_numpy(r.integers(12, 113, (1, N))).to(device)
+    tone = torch.from_numpy(r.integers(0, 11, (1, N))).to(device)
+    lang = torch.where(ids < 74, 1, 2)
+    prompt = torch.from_numpy(_prompt_audio(1, 20000, 1)).to(device)
+    dur = torch.full((1, N), 4.0, device=device)
+    noise = torch.from_numpy(r.standard_normal((1, 192, N * 2)).astype(np.float32)).to(device)
+    path = tmp_path / "out.wav"
+    wav = IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, output_path=path, dur=dur, noise=noise)
+    assert wav.dtype == torch.int16 and wav.shape == (N * 2 * 320,) and int(wav.abs().max()) >= 32000
+    again = IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, dur=dur, noise=noise)
+    assert torch.equal(wav, again)
+    mel_ttv, mel2 = IP.prompt_mels(mel_fn, prompt)
+    ref = IP.tts(models, ids, torch.tensor([N], device=device), tone, lang, mel_ttv,
+                 torch.tensor([mel_ttv.shape[2]], device=device), mel2,
+                 torch.tensor([mel2.shape[2]] * 2, device=device), dur=dur, noise=noise)[0]
+    assert torch.equal(wav, ref)
+    rate, back = wavfile.read(path)
+    assert rate == 16000 and np.array_equal(back, wav.cpu().numpy())
+
+
 def test_fused_layernorm_gemm_vs_torch(device):
     """hsp_conv1d_args.ln_c1: y = W LN(x) + b with the LayerNorm folded into the token GEMM (statistics from the
     staged input tile) against torch's two-pass LayerNorm + Linear; also that shapes outside the token-GEMM path
