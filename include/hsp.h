@@ -301,6 +301,26 @@ int hsp_power_mel_log_f32(const float* spec, int64_t s_bs, int32_t s_ld, const f
                           const int32_t* f_hi, float* out, int32_t B, int32_t n_freqs, int32_t n_mels,
                           int32_t T_out, float eps, void* stream);
 
+/* ------------------------------------------------ SURVEY.md §8(b) names (dispatching entry points) */
+/* The minimum export set of SURVEY.md §8(b) under its own names; each forwards to the entry points above.
+ * hsp_conv1d_f32: any weight-normed / plain Conv1d or Linear of the path with its fused prologue / epilogue
+ *   (PLAIN or GATE rows); picks the MFMA or the VALU kernel by shape exactly as the host mirror does
+ *   (stride != 1, Cin / Cout / Lout < 8 or the SiLU prologue -> hsp_conv1d_direct_f32).
+ * hsp_convtr1d_f32: ConvTranspose1d as its polyphase conv (rows == HSP_ROWS_SHUFFLE, weights packed with
+ *   hip_layers.convtr_pack_map): hierspeechpp_speechsynthesizer.py:292-300,430-436.
+ * hsp_wn_layer_f32: one layer of modules.WN (modules.py:156-175): `in_layer` (HSP_ROWS_GATE_WN: conv + g_l +
+ *   tanh*sigmoid), then the residual half `res` (x = (x + rs[:H]) * mask) and the skip half `skip`
+ *   (out += rs[H:]) of res_skip_layers; either of the two may be NULL (last layer: skip only).
+ * hsp_layernorm_modulate_f32: LayerNorm (no affine) + mask + modulate of the DiT blocks (modules.py:346-347,
+ *   409-410) = hsp_layernorm_mod_f32 without gamma / beta. */
+int hsp_conv1d_f32(const hsp_conv1d_args* a, void* stream);
+int hsp_convtr1d_f32(const hsp_conv1d_args* a, void* stream);
+int hsp_wn_layer_f32(const hsp_conv1d_args* in_layer, const hsp_conv1d_args* res, const hsp_conv1d_args* skip,
+                     void* stream);
+int hsp_layernorm_modulate_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, float eps,
+                               const float* mask, const float* shift, const float* scale, int64_t mod_bs,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,11 @@ SIGNATURES = {
     "hsp_peak_int16": (C.c_int, [_fp, C.c_int64, _fp, C.c_float, _fp, C.c_int64, C.c_int32, C.c_int64, _fp]),
     "hsp_copy_strided_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32,
                                        _fp]),
+    "hsp_conv1d_f32": (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
+    "hsp_convtr1d_f32": (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
+    "hsp_wn_layer_f32": (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs), _fp]),
+    "hsp_layernorm_modulate_f32": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp, _fp, _fp,
+                                             C.c_int64, _fp]),
     "hsp_stft_frames_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       _fp]),
     "hsp_power_mel_log_f32": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32,

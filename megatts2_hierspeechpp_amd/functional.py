@@ -75,6 +75,13 @@ def layernorm_mod(x, eps: float, mask=None, shift=None, scale=None, gamma=None, 
     if shift is not None:
         assert shift.stride(1) == 1 and scale.stride(1) == 1 and shift.stride(0) == scale.stride(0)
         mod_bs = shift.stride(0)
+    from . import hip_layers
+    if hip_layers.SURVEY_ABI and gamma is None and beta is None:   # SURVEY.md §8(b) name of the same launch
+        L.check(L.lib().hsp_layernorm_modulate_f32(L.fptr(x), L.fptr(y), B, Cc, T, float(eps),
+                                                   L.fptr(_c(mask)) if mask is not None else None,
+                                                   L.fptr(shift), L.fptr(scale), mod_bs, L.stream_ptr()),
+                "hsp_layernorm_modulate_f32")
+        return y
     L.check(L.lib().hsp_layernorm_mod_f32(L.fptr(x), L.fptr(y), B, Cc, T, float(eps),
                                           L.fptr(_c(mask)) if mask is not None else None,
                                           L.fptr(shift), L.fptr(scale), mod_bs, L.fptr(gamma), L.fptr(beta),

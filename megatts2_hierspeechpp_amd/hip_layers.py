@@ -41,8 +41,21 @@ def _zeros(device) -> torch.Tensor:
     return z
 
 
+# SURVEY.md §8(b) names its minimum C ABI (hsp_conv1d_f32, hsp_convtr1d_f32, hsp_wn_layer_f32,
+# hsp_layernorm_modulate_f32).  Those entry points dispatch to the kernel-level ones this module calls by
+# default; with SURVEY_ABI set (HSP_SURVEY_ABI=1) every launch goes through them instead - same kernels, same
+# results (tests/test_gpu_parity.py::test_survey_abi_names_give_identical_results).
+SURVEY_ABI = os.environ.get("HSP_SURVEY_ABI", "0") == "1"
+_DEFER = None  # a list while modules.WN collects the launches of one layer for hsp_wn_layer_f32
+
+
 def _launch(kind: str, fn, a, flops: int, nbytes: int):
     a.debug = DEBUG_FLAGS
+    if SURVEY_ABI:
+        if _DEFER is not None:
+            _DEFER.append(a)
+            return
+        fn = L.lib().hsp_convtr1d_f32 if a.rows == L.ROWS_SHUFFLE else L.lib().hsp_conv1d_f32
     hook = LAUNCH_HOOK
     if hook is None:
         L.check(fn(C.byref(a), L.stream_ptr()), kind)

@@ -4,11 +4,14 @@ arguments and state-dict keys (reference: modules.py).  Every tensor stays chann
 changes only.  All arithmetic is in libhsp.so."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 from torch import nn
 
 from . import _lib as L
 from . import functional as Fh
+from . import hip_layers
 from .hip_layers import Conv1d, HipLayer, Linear
 
 LRELU_SLOPE = 0.1  # modules.py:17
@@ -68,6 +71,8 @@ class WN(nn.Module):
         out = None
         for i in range(self.n_layers):
             cb = gc[:, 2 * H * i: 2 * H * (i + 1)] if gc is not None else None
+            if hip_layers.SURVEY_ABI:   # the layer's three launches as ONE hsp_wn_layer_f32 call
+                hip_layers._DEFER = []
             acts = self.in_layers[i](x, cbias=cb)
             if i < self.n_layers - 1:
                 x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
@@ -77,6 +82,11 @@ class WN(nn.Module):
                 # last layer: output = (output + rs) * x_mask   (modules.py:175-176)
                 out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None, mask=x_mask,
                                               mask_mode=L.MASK_NONE)
+            if hip_layers.SURVEY_ABI:
+                args, hip_layers._DEFER = hip_layers._DEFER, None
+                res_a = C.byref(args[1]) if len(args) == 3 else None
+                L.check(L.lib().hsp_wn_layer_f32(C.byref(args[0]), res_a, C.byref(args[-1]), L.stream_ptr()),
+                        "hsp_wn_layer_f32")
         return Fh.mask_mul(out, x_mask)
 
 

@@ -31,6 +31,25 @@ def test_golden(name, device):
         _close(o, r, f"{name}[{i}]")
 
 
+@pytest.mark.parametrize("name", ["wn_h192", "dit_block", "convtr_k11_s5", "generator", "infer_ragged"])
+def test_survey_abi_names_give_identical_results(name, device):
+    """The dispatching entry points named in SURVEY.md §8(b) (hsp_conv1d_f32, hsp_convtr1d_f32, hsp_wn_layer_f32,
+    hsp_layernorm_modulate_f32) run the same kernels: the golden cases through them == through the default path."""
+    from megatts2_hierspeechpp_amd import hip_layers
+    if name not in H.fixture_names():
+        pytest.skip(f"no fixture {name}")
+    meta, arrays = H.load_fixture(name)
+    base = H.run_hip(meta, arrays, device)
+    old, hip_layers.SURVEY_ABI = hip_layers.SURVEY_ABI, True
+    try:
+        outs = H.run_hip(meta, arrays, device)
+    finally:
+        hip_layers.SURVEY_ABI = old
+    for o, b_, r in zip(outs, base, H.outputs(arrays)):
+        _close(o, r, name)
+        assert np.array_equal(o, b_), f"{name}: SURVEY-named entry points changed the result"
+
+
 # ------------------------------------------------------------ (b) oracle, other sizes
 def _amp_case(device, C_, k, L, B, seed, fuse_max_c=None):
     from megatts2_hierspeechpp_amd import synth
