@@ -159,8 +159,8 @@ constexpr int ACT2_A2 = 1040;
 
 __device__ __forceinline__ void act2_compiler_fence() { asm volatile("" ::: "memory"); }
 
-// raw window of work item w into registers (phase A loads): replicate padding; p0 - 8 and L are
-// multiples of 4, so a float4 lies wholly inside the row or wholly outside it.
+// one work item = one segment [p0, p0 + n_out) of one (b, c) row; p0 - 8 and L are multiples of 4, so a
+// float4 of the raw window lies wholly inside the row or wholly outside it
 struct Act2Item {
   int p0, n_out, c;
   int64_t row_off;
