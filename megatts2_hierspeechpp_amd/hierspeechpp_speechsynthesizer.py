@@ -29,7 +29,7 @@ from . import activations
 from . import modules
 from .alias_free_torch import Activation1d
 from .commons import get_padding
-from .hip_layers import Conv1d, ConvTranspose1d, Linear, finalize as _finalize
+from .hip_layers import Conv1d, ConvTranspose1d, Linear, StackedLinearCT, finalize as _finalize
 from .styleencoder import StyleEncoder
 
 UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / analysis only
@@ -59,6 +59,13 @@ class ResidualCouplingBlock_Transformer(nn.Module):
             self.flows.append(modules.ResidualCouplingLayer_Transformer_simple(
                 channels, hidden_channels, kernel_size, dilation_rate, n_layers, mean_only=True))
             self.flows.append(modules.Flip())
+        # The adaLN_modulation Linears of all n_flows * n_layers DiT blocks read the same SiLU(c): their rows are
+        # stacked into ONE GEMM per forward (12 launches -> 1); the blocks keep the parameters (checkpoint keys).
+        lins = [blk.adaLN_modulation[1] for i in range(n_flows) for blk in self.flows[2 * i].enc_block]
+        for lin in lins:
+            lin.__dict__["_stacked_elsewhere"] = True
+        self.adaln_all = StackedLinearCT(lins)
+        self._mod_rows = lins[0].cout * n_layers   # rows per coupling layer
 
     def forward(self, x, x_mask, g=None, reverse=False):
         if not reverse:
@@ -66,10 +73,13 @@ class ResidualCouplingBlock_Transformer(nn.Module):
         c = self.cond_block[0](g.reshape(g.shape[0], -1), act=L.ACT_SILU)
         # every DiT block consumes SiLU(c) (adaLN_modulation = Sequential(SiLU, Linear)): apply it
         # once in the epilogue of the producing Linear instead of 12 times per flow
-        c_silu = self.cond_block[2](c, act=L.ACT_SILU)[:, :, 0]  # [B, hidden]
+        c_silu = self.cond_block[2](c, act=L.ACT_SILU)   # [B, hidden, 1]
+        mods = self.adaln_all(c_silu)                    # [B, n_flows * n_layers * 6 * hidden, 1]
+        R = self._mod_rows
         for i in reversed(range(self.n_flows)):
             x = self.flows[2 * i + 1](x, x_mask, reverse=True)                                  # Flip -> fresh tensor
-            x = self.flows[2 * i](x, x_mask, g=None, c_silu=c_silu, reverse=True, inplace=True)  # coupling, in place
+            x = self.flows[2 * i](x, x_mask, g=None, mods=mods[:, i * R:(i + 1) * R], reverse=True,
+                                  inplace=True)                                                 # coupling, in place
         return x
 
 

@@ -228,11 +228,15 @@ class Conv1d(_ConvBase):
         return g, b
 
     def hsp_requests(self):
+        if self.__dict__.get("_stacked_elsewhere"):   # rows live in a StackedLinearCT: parameters only
+            return []
         fused = self.__dict__.get("_pre_norm") is not None
         return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias or fused else []) + \
             ([("c1", self.cout)] if fused else [])
 
     def hsp_fill(self, arena, materialize):
+        if self.__dict__.get("_stacked_elsewhere"):
+            return
         fused = self.__dict__.get("_pre_norm") is not None
         self._w = arena.view(self, "w")
         self._b = arena.view(self, "b") if self.has_bias or fused else None

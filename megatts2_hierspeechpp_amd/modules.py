@@ -135,11 +135,14 @@ class DiTConVBlock(nn.Module):
         # nn.Sequential(SiLU, Linear) in the reference: index 1 carries the parameters
         self.adaLN_modulation = nn.ModuleList([nn.Identity(), Linear(hidden_size, 6 * hidden_size)])
 
-    def forward(self, x, c, x_mask, c_silu=None):
-        """``c_silu`` = SiLU(c) precomputed by the caller (the same for every block of a flow)."""
+    def forward(self, x, c, x_mask, c_silu=None, mod=None):
+        """``c_silu`` = SiLU(c) precomputed by the caller (the same for every block of a flow); ``mod`` =
+        this block's adaLN_modulation output [B, 6C, 1] when the caller ran all blocks' Linears as one GEMM."""
         C = self.hidden_size
         x = Fh.mask_mul(x, x_mask)
-        if c_silu is not None:
+        if mod is not None:
+            pass
+        elif c_silu is not None:
             mod = self.adaLN_modulation[1](c_silu)           # [B, 6C, 1]
         else:
             mod = self.adaLN_modulation[1](c, silu_in=True)  # [B, 6C, 1]
@@ -170,13 +173,15 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
                                         for _ in range(n_layers)])
         self.post = Conv1d(hidden_channels, self.half_channels, 1)
 
-    def forward(self, x, x_mask, g=None, reverse=False, inplace=False, c_silu=None):
+    def forward(self, x, x_mask, g=None, reverse=False, inplace=False, c_silu=None, mods=None):
+        """``mods`` [B, n_layers * 6 * hidden, 1]: the adaLN outputs of this layer's blocks, stacked."""
         if not reverse:
             raise NotImplementedError("training direction (logdet) is out of scope")
         half = self.half_channels
         h = self.pre(x[:, :half], mask=x_mask, mask_mode=L.MASK_PRE)
-        for blk in self.enc_block:
-            h = blk(h, g, x_mask, c_silu=c_silu)
+        R = 6 * self.hidden_channels
+        for j, blk in enumerate(self.enc_block):
+            h = blk(h, g, x_mask, c_silu=c_silu, mod=None if mods is None else mods[:, j * R:(j + 1) * R])
         out = x if inplace else x.clone()
         # x1 <- (x1 - post(h) * mask) * mask          (modules.py:473,486)
         self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, half:], out=out[:, half:])
