@@ -135,11 +135,14 @@ class DiTConVBlock(nn.Module):
         # nn.Sequential(SiLU, Linear) in the reference: index 1 carries the parameters
         self.adaLN_modulation = nn.ModuleList([nn.Identity(), Linear(hidden_size, 6 * hidden_size)])
 
-    def forward(self, x, c, x_mask, c_silu=None, mod=None):
+    def forward(self, x, c, x_mask, c_silu=None, mod=None, premasked=False):
         """``c_silu`` = SiLU(c) precomputed by the caller (the same for every block of a flow); ``mod`` =
-        this block's adaLN_modulation output [B, 6C, 1] when the caller ran all blocks' Linears as one GEMM."""
+        this block's adaLN_modulation output [B, 6C, 1] when the caller ran all blocks' Linears as one GEMM;
+        ``premasked``: x is already zero outside the mask (the output of a masked launch), so the leading
+        ``x * x_mask`` of modules.py:407 is the identity and is not launched."""
         C = self.hidden_size
-        x = Fh.mask_mul(x, x_mask)
+        if not premasked:
+            x = Fh.mask_mul(x, x_mask)
         if mod is not None:
             pass
         elif c_silu is not None:
@@ -181,7 +184,9 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
         h = self.pre(x[:, :half], mask=x_mask, mask_mode=L.MASK_PRE)
         R = 6 * self.hidden_channels
         for j, blk in enumerate(self.enc_block):
-            h = blk(h, g, x_mask, c_silu=c_silu, mod=None if mods is None else mods[:, j * R:(j + 1) * R])
+            # `pre` and every block's last launch multiply by the mask before the residual add: h stays masked
+            h = blk(h, g, x_mask, c_silu=c_silu, mod=None if mods is None else mods[:, j * R:(j + 1) * R],
+                    premasked=True)
         out = x if inplace else x.clone()
         # x1 <- (x1 - post(h) * mask) * mask          (modules.py:473,486)
         self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, half:], out=out[:, half:])
