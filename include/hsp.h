@@ -141,6 +141,16 @@ typedef struct hsp_conv1d_args {
    * nn.LayerNorm -> nn.Linear pairs of ttv_v1/transformer_mega.py:125-131.  NULL = off. */
   const float* ln_c1;
   float ln_eps;
+  /* Second output of a 1x1 token GEMM (token-GEMM path only; any other shape is refused with HSP_EINVAL).
+   * With split_row > 0 (a multiple of 64) the rows [split_row, Cout) are written to
+   *   y2[b][m - split_row][t] = (accumulate2 ? y2 : 0) + (acc[m, t] + bias[m]) [* mask per mask_mode2]
+   * while the rows [0, split_row) keep y / res / accumulate / mask_mode (indexed by m).  One GEMM then serves the
+   * two halves of modules.WN's res_skip_layers (modules.py:166-174): x = (x + rs[:H]) * mask and out += rs[H:]. */
+  int32_t split_row;
+  int32_t accumulate2;
+  int32_t mask_mode2;
+  float* y2;
+  int64_t y2_bs, y2_cs;
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Two kernels sit

@@ -43,6 +43,8 @@ class Conv1dArgs(C.Structure):
         ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64),
         ("accumulate", C.c_int32), ("post_scale", C.c_float), ("debug", C.c_int32),
         ("ln_c1", _fp), ("ln_eps", C.c_float),
+        ("split_row", C.c_int32), ("accumulate2", C.c_int32), ("mask_mode2", C.c_int32), ("y2", _fp),
+        ("y2_bs", C.c_int64), ("y2_cs", C.c_int64),
     ]
 
 

@@ -68,7 +68,7 @@ extern "C" int hsp_conv1d_direct_f32(const hsp_conv1d_args* ap, void* stream) {
   if (a.stride < 1 || a.dil < 1 || a.rows != HSP_ROWS_PLAIN || a.Cout > a.M || a.w_ld < a.M) return HSP_EINVAL;
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_SILU) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
-  if (a.ln_c1) return HSP_EINVAL;  // fused LayerNorm: token-GEMM path only
+  if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused LayerNorm / second output: token-GEMM path only
   const int64_t total = (int64_t)a.B * a.Cout * a.Lout;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 262144) blocks = 262144;

@@ -735,12 +735,12 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // "short": even 128 x 128 tiles would leave CUs idle; prefer small tiles with deep chunks so
   // that every CU gets work and each tile sees few global-load round trips
   const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B < 256;
-  if ((short_seq || a.ln_c1) && !(a.debug & 128)) {
+  if ((short_seq || a.ln_c1 || a.split_row) && !(a.debug & 128)) {
     // 1x1 GEMMs over a few thousand token columns: the latency-oriented kernel (hsp_tokgemm.hip)
     const int e = hsp_tokgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
-  if (a.ln_c1) return HSP_EINVAL;  // the fused input LayerNorm exists on the token-GEMM path only
+  if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused input LayerNorm / second output: token-GEMM path only
   if (short_seq) {
     if (gated) return launch<S64G>(a, s, plan_out);
     if (a.M > 32) return launch<S64>(a, s, plan_out);

@@ -158,9 +158,15 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
   const int nc = n < a.ncols ? n : a.ncols - 1;
   const int mb = m0 + wm * 32 + 4 * half;
   float bv[NR], rv[NR], yv[NR], cs[NR], c1[NR];
-  const float mk = a.mask_mode != HSP_MASK_NONE ? a.mask[(int64_t)b * a.mask_bs + nc] : 1.0f;
-  const float* resb = a.res ? a.res + (int64_t)b * a.res_bs + nc : nullptr;
-  float* yb = a.y + (int64_t)b * a.y_bs + nc;
+  // second output (hsp_conv1d_args.split_row): whole row tiles at or beyond split_row use the second parameter set
+  const bool second = a.split_row > 0 && m0 >= a.split_row;
+  const int mo = second ? a.split_row : 0;
+  const int mmode = second ? a.mask_mode2 : a.mask_mode;
+  const int accum = second ? a.accumulate2 : a.accumulate;
+  const int64_t ycs = second ? a.y2_cs : a.y_cs;
+  const float mk = mmode != HSP_MASK_NONE ? a.mask[(int64_t)b * a.mask_bs + nc] : 1.0f;
+  const float* resb = (a.res && !second) ? a.res + (int64_t)b * a.res_bs + nc : nullptr;
+  float* yb = (second ? a.y2 + (int64_t)b * a.y2_bs : a.y + (int64_t)b * a.y_bs) + nc;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int r = NR * grp + i;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     bv[i] = t;
     cs[i] = a.cscale ? a.cscale[(int64_t)b * a.cscale_bs + mc] : 1.0f;
     rv[i] = resb ? resb[(int64_t)mc * a.res_cs] : 0.0f;
-    yv[i] = a.accumulate ? yb[(int64_t)mc * a.y_cs] : 0.0f;
+    yv[i] = accum ? yb[(int64_t)(mc - mo) * ycs] : 0.0f;
     c1[i] = a.ln_c1 ? a.ln_c1[mc] : 0.0f;
   }
   float A0[4], B0[4], A1[4], B1[4];
@@ -231,13 +237,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     if (m >= a.Cout) continue;
     float v = a.ln_c1 ? fmaf(rstd, fmaf(-mean, c1[i], fin[i]), bv[i]) : fin[i] + bv[i];
     v = hsp_apply_act(v, a.act);                        // then the order of hsp_epilogue_store
-    if (a.mask_mode & HSP_MASK_PRE) v *= mk;
+    if (mmode & HSP_MASK_PRE) v *= mk;
     v *= cs[i];
     v *= a.scale;
     v += rv[i];
-    if (a.mask_mode & HSP_MASK_POST) v *= mk;
+    if (mmode & HSP_MASK_POST) v *= mk;
     v += yv[i];
-    yb[(int64_t)m * a.y_cs] = v * a.post_scale;
+    yb[(int64_t)(m - mo) * ycs] = v * a.post_scale;
   }
 }
 
@@ -267,6 +273,10 @@ int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) 
   if ((a.Cin & 3) || (a.ncols & 3) || (a.x_bs & 3) || (a.x_cs & 3) || !al16(a.x) || !al16(a.w) || (a.w_ld & 3)) return -1;
   if (a.Cin < 64 || a.Cin > 4096) return -1;
   if (a.ln_c1 && !(a.ln_eps > 0.0f)) return -1;
+  if (a.split_row) {  // second output: whole 64-row tiles, its own 16-B independent destination
+    if (a.split_row < 0 || (a.split_row % TG_BM) || a.split_row >= a.Cout || !a.y2 || a.ln_c1) return -1;
+    if (a.mask_mode2 != HSP_MASK_NONE && !a.mask) return -1;
+  }
   const int n_mt = (a.M + TG_BM - 1) / TG_BM, n_nt = (a.ncols + TG_BN - 1) / TG_BN;
   const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
   if (blocks <= 0 || blocks > 0x7fffffff) return -1;

@@ -49,7 +49,9 @@ SURVEY_ABI = os.environ.get("HSP_SURVEY_ABI", "0") == "1"
 _DEFER = None  # a list while modules.WN collects the launches of one layer for hsp_wn_layer_f32
 
 
-def _launch(kind: str, fn, a, flops: int, nbytes: int):
+def _launch(kind: str, fn, a, flops: int, nbytes: int, soft: bool = False):
+    """``soft``: return the status instead of raising on HSP_EINVAL (a shape the requested fusion does not
+    cover; the caller then issues the un-fused launches)."""
     a.debug = DEBUG_FLAGS
     if SURVEY_ABI:
         if _DEFER is not None:
@@ -58,13 +60,20 @@ def _launch(kind: str, fn, a, flops: int, nbytes: int):
         fn = L.lib().hsp_convtr1d_f32 if a.rows == L.ROWS_SHUFFLE else L.lib().hsp_conv1d_f32
     hook = LAUNCH_HOOK
     if hook is None:
-        L.check(fn(C.byref(a), L.stream_ptr()), kind)
-        return
+        rc = fn(C.byref(a), L.stream_ptr())
+        if soft and rc == L.EINVAL:
+            return rc
+        L.check(rc, kind)
+        return 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    L.check(fn(C.byref(a), L.stream_ptr()), kind)
+    rc = fn(C.byref(a), L.stream_ptr())
+    if soft and rc == L.EINVAL:
+        return rc
+    L.check(rc, kind)
     e1.record()
     hook(kind, flops, nbytes, e0, e1, a)
+    return 0
 
 
 # ------------------------------------------------------------------ index maps (host logic)
@@ -260,9 +269,13 @@ class Conv1d(_ConvBase):
     # ----------------------------------------------------------------------------
     def forward(self, x, *, act1d=None, lrelu: Optional[float] = None, silu_in=False, act=L.ACT_NONE, cbias=None,
                 mask=None, mask_mode=L.MASK_NONE, cscale=None, scale=1.0, res=None, out=None, accumulate=False,
-                post_scale=1.0, force_direct=False, row_range=None):
+                post_scale=1.0, force_direct=False, row_range=None, split_out=None):
         """``row_range=(r0, r1)`` computes only output channels [r0, r1) (PLAIN rows, r0 % 4 == 0):
-        the WN res/skip layer is one parameter set feeding two differently-fused launches."""
+        the WN res/skip layer is one parameter set feeding two differently-fused launches.
+        ``split_out=(split_row, out2, accumulate2)``: ONE launch for both halves of such a layer
+        (hsp_conv1d_args.split_row): rows [0, split_row) -> the usual output with this call's epilogue, rows
+        [split_row, cout) -> ``out2`` (+= if accumulate2; allocated when None).  Returns (out, out2), or None when
+        the library has no fused kernel for the shape (the caller then launches the halves separately)."""
         self._require_ready()
         B, Cin, Lin = x.shape
         assert Cin == self.cin, (Cin, self.cin)
@@ -274,6 +287,14 @@ class Conv1d(_ConvBase):
             assert not gated and r0 % 4 == 0 and 0 <= r0 < r1 <= self.cout
             cout = r1 - r0
         Lout = (Lin + 2 * self.padding - self.dilation * (self.k - 1) - 1) // self.stride + 1
+        out2 = None
+        if split_out is not None:
+            split_row, out2, acc2 = split_out
+            assert row_range is None and not gated and self.k == 1 and 0 < split_row < self.cout
+            cout = split_row
+            if out2 is None:
+                assert not acc2
+                out2 = torch.empty(B, self.cout - split_row, Lout, dtype=torch.float32, device=x.device)
         if out is None:
             out = torch.empty(B, cout, Lout, dtype=torch.float32, device=x.device)
         a = L.Conv1dArgs()
@@ -305,6 +326,14 @@ class Conv1d(_ConvBase):
         # algorithmic traffic: input once, output once (+ residual / accumulate reads), weights once
         nbytes = 4 * (B * Cin * Lin + B * cout * Lout * (1 + (res is not None) + bool(accumulate))
                       + rows_full * Cin * self.k)
+        if split_out is not None:
+            a.Cout = self.cout                      # rows [split_row, cout) go to the second output
+            a.split_row, a.accumulate2, a.mask_mode2 = split_row, int(bool(acc2)), L.MASK_NONE
+            a.y2, a.y2_bs, a.y2_cs = L.fptr(out2), out2.stride(0), out2.stride(1)
+            flops = 2 * B * self.cout * Cin * Lout
+            nbytes += 4 * B * (self.cout - split_row) * Lout * (1 + bool(acc2))
+            rc = _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes, soft=True)
+            return None if rc else (out, out2)
         if direct:
             _launch("hsp_conv1d_direct_f32", L.lib().hsp_conv1d_direct_f32, a, flops, nbytes)
         else:

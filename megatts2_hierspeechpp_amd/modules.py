@@ -75,6 +75,15 @@ class WN(nn.Module):
                 hip_layers._DEFER = []
             acts = self.in_layers[i](x, cbias=cb)
             if i < self.n_layers - 1:
+                # both halves of res_skip in one token-GEMM launch where the library has it (T = 200 frames);
+                # two launches otherwise (and under SURVEY_ABI, whose hsp_wn_layer_f32 takes the halves apart)
+                both = None
+                if not hip_layers.SURVEY_ABI and H % 64 == 0:
+                    both = self.res_skip_layers[i](acts, res=x, mask=x_mask, mask_mode=L.MASK_POST,
+                                                   split_out=(H, out, out is not None))
+                if both is not None:
+                    x, out = both
+                    continue
                 x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
                 out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
                 x = x_new

@@ -429,6 +429,42 @@ def test_tts_from_prompt_waveform(mel_fn, device, tmp_path):
     assert rate == 16000 and np.array_equal(back, wav.cpu().numpy())
 
 
+def test_second_output_gemm_matches_two_launches(device):
+    """hsp_conv1d_args.split_row: one token-GEMM launch for the two row halves of a WN res_skip layer
+    (modules.py:166-174) == the two separate launches, bit for bit; shapes without a fused kernel are refused
+    (the host then falls back) instead of computing something else."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    g = torch.Generator().manual_seed(3)
+    for H_, B, T in [(192, 3, 200), (64, 2, 52), (512, 1, 120)]:
+        lay = Conv1d(H_, 2 * H_, 1, weight_norm=True)
+        with torch.no_grad():
+            for p_ in lay.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+            lay.weight_g.fill_(0.5)
+        finalize(lay, device)
+        acts = torch.randn(B, H_, T, generator=g).to(device)
+        x = torch.randn(B, H_, T, generator=g).to(device)
+        mask = (torch.rand(B, 1, T, generator=g) > 0.2).float().to(device)
+        prev = torch.randn(B, H_, T, generator=g).to(device)
+        x_ref = lay(acts, row_range=(0, H_), res=x, mask=mask, mask_mode=L.MASK_POST)
+        out_ref = lay(acts, row_range=(H_, 2 * H_), out=prev.clone(), accumulate=True)
+        out_new = lay(acts, row_range=(H_, 2 * H_))
+        both = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, prev.clone(), True))
+        assert both is not None, (H_, B, T)
+        assert torch.equal(both[0], x_ref) and torch.equal(both[1], out_ref)
+        first = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, None, False))
+        assert torch.equal(first[0], x_ref) and torch.equal(first[1], out_new)
+    # no fused kernel: split row off the 64-row tile grid, or a column count the token GEMM does not take
+    lay = Conv1d(96, 192, 1, weight_norm=True)
+    finalize(lay, device)
+    a96 = torch.randn(2, 96, 40, generator=g).to(device)
+    assert lay(a96, split_out=(96, None, False)) is None
+    lay = Conv1d(64, 128, 1, weight_norm=True)
+    finalize(lay, device)
+    assert lay(torch.randn(2, 64, 37, generator=g).to(device), split_out=(64, None, False)) is None
+
+
 def test_fused_layernorm_gemm_vs_torch(device):
     """hsp_conv1d_args.ln_c1: y = W LN(x) + b with the LayerNorm folded into the token GEMM (statistics from the
     staged input tile) against torch's two-pass LayerNorm + Linear; also that shapes outside the token-GEMM path
