@@ -3,25 +3,35 @@
 configs[1]), 16 kHz output samples / s over the whole job + RTF.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-A step = one ``SynthesizerTrn.infer`` pass (style encoder -> SF prior encoder -> two
-reversed DiT coupling flows -> source network -> BigVGAN-style generator) over one batch
-of synthetic (mel, w2v, f0) already resident in HBM; weights are the synthetic recipe
-(no checkpoints exist offline).  Weak scaling: every rank synthesises its own 32
-utterances; rank 0 packs the weights and broadcasts the arena over RCCL.
+N > 1 works both ways: under a launcher (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`, one rank per GPU over RCCL) and on its own --
+with WORLD_SIZE unset the parent process starts that launcher as a child BEFORE anything touches the GPU
+(never a re-exec), relays rank 0's JSON line and exits with the child's status.
+
+A step = one ``SynthesizerTrn.infer`` pass (style encoder -> SF prior encoder -> two reversed DiT coupling
+flows -> source network -> BigVGAN-style generator) over this rank's shard of a global batch of 32 x N
+utterances (parallel.shard_range: contiguous blocks, no data-path collective), synthetic (mel, w2v, f0) already
+resident in HBM; weights are the synthetic recipe (no checkpoints exist offline).  Rank 0 packs the weights,
+every other rank only lays the arena out and receives the bytes by ONE chunked RCCL broadcast.
 
 Printed JSON (one line, rank 0): metric/value per the driver contract plus
-  roofline     -- for the dominant kernel (conv1d_mfma_kernel): algorithmic FLOP of all
-                  its launches in one step / their summed duration, timed live with
-                  events on the launch stream, against the 157.3 TFLOP/s fp32 MFMA peak
-  cpu_baseline -- the CPU oracle (oracle/hsp_oracle.py) on this box's host cores on a
-                  bounded sample (B=1 x 4 s), N=1 only.
+  broadcast_ms, rank_ms_per_step {min, max}, rccl_world -- the multi-GPU side
+  event_median_ms -- median of the K steps, each bracketed by a HIP-event pair (SURVEY.md 8d protocol)
+  roofline      -- dominant kernel (conv1d_mfma_kernel): algorithmic FLOP of all its launches in one step /
+                   their summed duration, timed live with events on the launch stream, against the
+                   157.3 TFLOP/s fp32 MFMA peak; `traffic` from the committed PMC profile when it was
+                   taken on this very build and launch mix, else null with the reason
+  cpu_baseline  -- the CPU oracle (oracle/hsp_oracle.py) on this box's host cores: configs[0] (1 x 1 s) and a
+                   bounded sample of configs[1] (8 x 4 s), N=1 only
+  extra_configs -- configs[2] (full text->wav, batch 16) and configs[3] (vocoder + SpeechSR48, batch 32),
+                   N=1 only (tools/bench_extra.py)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,228 +40,402 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
+METRIC = "16kHz audio samples/sec (whole node) + RTF, HierSpeech++ vocoder batch=32"
 
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
-    ap.add_argument("--seconds", type=float, default=4.0, help="audio seconds per utterance")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--dump-launches", default=None, help="write a per-shape table of the conv launches here")
-    args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from megatts2_hierspeechpp_amd import hip_layers, parallel, synth
-    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
-
-    rank, local_rank, world = parallel.init_distributed("nccl")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    cfg = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,
+VOC_CFG = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,
                p_dropout=0.1, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
                upsample_rates=[4, 5, 4, 2, 2], upsample_initial_channel=1024, upsample_kernel_sizes=[8, 11, 8, 4, 4],
                gin_channels=256)
-    net = SynthesizerTrn(641, 61440 // 320, **cfg)
-    sd_np = None
-    if rank == 0:  # only rank 0 materialises weights; the others receive the packed arena
-        sd_np = {k: synth.synth_tensor(k, tuple(v.shape), 0) for k, v in net.state_dict().items()}
-        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
-    arena = parallel.finalize_distributed(net, dev, src=0)
 
-    B, T = args.batch, int(round(args.seconds * 50))
-    inp = synth.synth_inputs(B, T, seed=20240 + rank)
-    d = lambda k: torch.from_numpy(inp[k]).to(dev)
-    mel, w2v, length, f0, noise = d("mel"), d("w2v"), d("length"), d("f0"), d("noise")
 
-    def eager_step():
-        return net.infer(mel, w2v, length, f0, noise=noise)
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (global batch = batch x gpus)")
+    ap.add_argument("--seconds", type=float, default=4.0, help="audio seconds per utterance")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2] and configs[3])")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--dump-launches", default=None, help="write a per-shape table of the conv launches here")
+    return ap.parse_args(argv)
 
-    # The whole forward (~830 launches) is captured once into a hipGraph and replayed:
-    # every launch of a step still executes, only the host-side submission cost goes.
-    eager_step()  # also sets kernel attributes (dynamic LDS sizes) outside the capture
-    torch.cuda.synchronize()
-    if args.no_graph:
-        step = eager_step
-    else:
+
+# ------------------------------------------------------------------------ self-launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` as a CHILD process (this
+    parent has not imported torch and never touches the GPU), relay its output, return its exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result line\n")
+        rc = 1
+    if line is not None:
+        print(line, flush=True)
+    return rc
+
+
+# ------------------------------------------------------------------------ workload
+class VocoderWorkload:
+    """configs[1]: SynthesizerTrn.infer on this rank's utterances."""
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        from megatts2_hierspeechpp_amd import synth
+        from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
+        self.args, self.rank, self.world, self.dev = args, rank, world, dev
+        self.frames = int(round(args.seconds * 50))
+        self.model = SynthesizerTrn(641, 61440 // 320, **VOC_CFG)
+        self.sd_np = None
+        if rank == 0:  # only rank 0 materialises weights; the others receive the packed arena
+            self.sd_np = {k: synth.synth_tensor(k, tuple(v.shape), 0) for k, v in self.model.state_dict().items()}
+            self.model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd_np.items()})
+        self.samples_per_utterance = 320 * self.frames
+
+    def prepare(self, lo, hi):
+        import torch
+        from megatts2_hierspeechpp_amd import synth
+        self.B = hi - lo
+        inp = synth.synth_inputs(self.B, self.frames, seed=20240 + lo)
+        self.inp = {k: torch.from_numpy(v).to(self.dev) for k, v in inp.items()}
+
+    def eager_step(self):
+        d = self.inp
+        return self.model.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+
+    def make_step(self):
+        """The whole forward (~800 launches) is captured once into a hipGraph and replayed: every launch of a
+        step still executes, only the host-side submission cost goes."""
+        import torch
+        self.eager_step()  # also raises the kernels' dynamic-LDS limits outside the capture
+        torch.cuda.synchronize()
+        if self.args.no_graph:
+            return self.eager_step
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            static_out = eager_step()
+            static_out = self.eager_step()
 
         def step():
             graph.replay()
             return static_out
+        return step
+
+    def check(self, out):
+        import torch
+        o = out[0]
+        assert o.shape == (self.B, 1, 320 * self.frames) and bool(torch.isfinite(o).all())
+
+    def describe(self, world):
+        a = self.args
+        return {"workload": f"vocoder-only infer(): {a.batch} utterances x {a.seconds:g} s per GPU "
+                            f"(BASELINE.json configs[1]), synthetic weights", "batch_per_gpu": a.batch,
+                "frames": self.frames, "global_batch": a.batch * world,
+                "parallelism": f"dp{world} (contiguous utterance shards of the global batch, one RCCL weight broadcast)",
+                "launch_mode": "eager" if a.no_graph else "hipGraph replay of the captured step"}
+
+
+def run_bench(args, make_workload, backend="nccl", device=None):
+    """The control flow of one rank (N = 1 included).  `make_workload(args, rank, world, dev)` returns an object
+    with .model (has .finalize(device, materialize)), .prepare(lo, hi), .make_step(), .check(out),
+    .samples_per_utterance and .describe(world).  Returns (result dict or None on ranks != 0, workload)."""
+    import torch
+    import torch.distributed as dist
+    from megatts2_hierspeechpp_amd import parallel
+
+    rank, local_rank, world = parallel.init_distributed(backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    dev = device if device is not None else torch.device("cuda", local_rank)
+    on_gpu = dev.type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    if on_gpu:
+        torch.cuda.set_device(dev)
+
+    wl = make_workload(args, rank, world, dev)
+    # weights: rank 0 folds + packs, everyone else lays the same arena out; one chunked broadcast
+    sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    arena = parallel.finalize_distributed(wl.model, dev, src=0)
+    sync()
+    broadcast_ms = parallel.barrier_max(1e3 * (time.perf_counter() - t0), dev)
+
+    lo, hi = parallel.shard_range(args.batch * world, rank, world)
+    wl.prepare(lo, hi)
+    step = wl.make_step()
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
+    events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        o, _ = step()
-    torch.cuda.synchronize()
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = step()
+        if on_gpu:
+            e1.record()
+            events.append((e0, e1))
+    sync()
+    local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = parallel.barrier_max(time.perf_counter() - t0, dev)
-    assert o.shape == (B, 1, 320 * T) and bool(torch.isfinite(o).all())
+    per_rank = parallel.gather_floats(1e3 * local / args.steps, dev)
+    wl.check(out)
 
-    samples_per_step = world * B * 320 * T
+    n_utt = args.batch * world
+    samples_per_step = n_utt * wl.samples_per_utterance
     audio_s_per_step = samples_per_step / 16000.0
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = samples_per_step * args.steps / elapsed
+    result = None
+    if rank == 0:
+        cfg = wl.describe(world)
+        cfg["weights_mb"] = arena.buffer.numel() * 4 / 1e6
+        cfg["shard_of_rank0"] = [lo, hi]
+        result = {
+            "metric": METRIC, "value": samples_per_step * args.steps / elapsed, "unit": "samples/s",
+            "rtf": (elapsed / args.steps) / audio_s_per_step, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
+            "broadcast_ms": broadcast_ms, "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)},
+            "rccl_world": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend if world > 1 else None,
+        }
+        if events:
+            import numpy as np
+            result["event_median_ms"] = float(np.median([a.elapsed_time(b) for a, b in events]))
+    return result, wl
 
-    result = {
-        "metric": "16kHz audio samples/sec (whole node) + RTF, HierSpeech++ vocoder batch=32",
-        "value": value, "unit": "samples/s", "rtf": (elapsed / args.steps) / audio_s_per_step,
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"vocoder-only infer(): {B} utterances x {args.seconds:g} s per GPU "
-                               f"(BASELINE.json configs[1]), synthetic weights", "batch_per_gpu": B,
-                   "frames": T, "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, "
-                   "one RCCL weight broadcast)", "weights_mb": arena.buffer.numel() * 4 / 1e6,
-                   "launch_mode": "eager" if args.no_graph else "hipGraph replay of the captured step"},
-    }
 
-    # ---- roofline of the dominant kernel, measured live (one extra instrumented step)
-    if not args.no_roofline:
-        # launches must run back to back on one stream here: with the AMP chains / batch groups on
-        # side streams the event-bracketed durations of concurrent kernels would overlap
-        from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
-        saved = (hss.AMP_STREAMS, hss.FRONT_SPLITS)
-        hss.AMP_STREAMS, hss.FRONT_SPLITS = 0, 1
-        rec = []
-        import ctypes as C
-        from megatts2_hierspeechpp_amd import _lib as L
+# ------------------------------------------------------------------------ roofline (vocoder, live)
+def _build_id():
+    """what the committed PMC traffic file must match: sha256 of the built library"""
+    import hashlib
+    from megatts2_hierspeechpp_amd import _lib as L
+    with open(L.LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
 
-        def hook(kind, fl, nb, e0, e1, la):
-            # two kernels sit behind hsp_conv1d_mfma_f32: ask the library which one this launch took
-            if kind == "hsp_conv1d_mfma_f32":
-                plan = (C.c_int32 * 4)()
-                L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
-                kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else "hsp_conv1d_mfma_f32/tokgemm"
-            rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
 
-        from megatts2_hierspeechpp_amd import functional as Fh
-        act_rec = []
-        Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
-        hip_layers.LAUNCH_HOOK = hook
-        eager_step()
+def vocoder_roofline(args, wl, result):
+    import ctypes as C
+    import torch
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from megatts2_hierspeechpp_amd import hip_layers
+    # launches must run back to back on one stream here: with the AMP chains / batch groups on
+    # side streams the event-bracketed durations of concurrent kernels would overlap
+    saved = (hss.AMP_STREAMS, hss.FRONT_SPLITS)
+    hss.AMP_STREAMS, hss.FRONT_SPLITS = 0, 1
+    rec, act_rec = [], []
+
+    def hook(kind, fl, nb, e0, e1, la):
+        # two kernels sit behind hsp_conv1d_mfma_f32: ask the library which one this launch took
+        if kind == "hsp_conv1d_mfma_f32":
+            plan = (C.c_int32 * 4)()
+            L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
+            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else "hsp_conv1d_mfma_f32/tokgemm"
+        rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
+
+    Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
+    hip_layers.LAUNCH_HOOK = hook
+    try:
+        wl.eager_step()
         torch.cuda.synchronize()
+    finally:
         hip_layers.LAUNCH_HOOK = None
         Fh.ACT_HOOK = None
         hss.AMP_STREAMS, hss.FRONT_SPLITS = saved
-        mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
-        tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32/tokgemm"]
-        if args.dump_launches and rank == 0:
-            agg = {}
-            for kind, fl, nb, e0, e1, shp in rec:
-                k = (kind,) + shp
-                n, f, m = agg.get(k, (0, 0, 0.0))
-                agg[k] = (n + 1, f + fl, m + e0.elapsed_time(e1))
-            with open(args.dump_launches, "w") as fh:
-                fh.write("kind Cin Cout K dil Lout prologue rows | launches gflop ms TF/s\n")
-                for k, (n, f, m) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-                    fh.write(f"{k[0][4:].replace('_f32', ''):14s} {k[1]:5d} {k[2]:5d} {k[3]:3d} {k[4]:2d} {k[5]:6d} {k[6]} {k[7]} | "
-                             f"{n:4d} {f / 1e9:10.1f} {m:9.3f} {f / (m * 1e-3) / 1e12:7.2f}\n")
-        tot_ms = sum(m for _, _, m in mf)
-        tot_fl = sum(f for f, _, _ in mf)
-        tot_b = sum(b for _, b, _ in mf)
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        # HBM bytes of the same kernel from the PMC counters: measured by tools/pmc_traffic.sh (rocprofv3
-        # cannot wrap a run from inside) and committed under profiles/; only quoted for the same workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("batch_per_gpu") == B and tj.get("frames") == T:
-                traffic = tj["conv1d_mfma_bytes_per_step"] / max(len(mf), 1)  # same bytes, this pass's launch count
-        except (OSError, KeyError, ValueError):
-            pass
-        result["roofline"] = {
-            "kernel": "conv1d_mfma_kernel (all tile configs; the 1x1 token-GEMM launches of the same entry point "
-                      "are excluded: %d launches, %.2f ms per step)" % (len(tg), sum(m for _, _, m in tg)),
-            "bound": "mfma", "achieved": ach,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate passes, each scaled by the factor "
-                            "calibrated on a known-bytes launch of this kernel: profiles/r01_traffic.json)",
-            "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
-            "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
-            "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,
-            "hbm_frac_of_8TBs": (tot_b / (tot_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
-            "share_of_step_time_single_stream": tot_ms / ms_per_step,
-            "timing": "one extra step, launches serialised on one stream, event pair per launch",
-        }
-        if act_rec:
-            # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
-            a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)
-            a_b = sum(nb for nb, _, _ in act_rec)
-            a_gbs = a_b / (a_ms * 1e-3) / 1e9
-            result["roofline_activation"] = {
-                "kernel": "act1d_seg_kernel (hsp_act1d_snakebeta_f32)", "bound": "hbm", "achieved": a_gbs,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_gbs / HBM_PEAK_GBS, "launches_per_step": len(act_rec),
-                "kernel_ms_per_step": a_ms, "algorithmic_mb_per_step": a_b / 1e6,
-                "algorithmic_bytes": "one fp32 read + one fp32 write per element", "traffic": None,
-                "timing": "same pass as `roofline`",
-            }
-            try:  # PMC bytes of the same kernel (profiles/r01_traffic.json; FETCH_SIZE doubled as the guide prescribes)
-                if tj.get("batch_per_gpu") == B and tj.get("frames") == T:
-                    result["roofline_activation"]["traffic"] = tj["act1d_seg_bytes_per_step"] / len(act_rec)
-                    result["roofline_activation"]["traffic_unit"] = "HBM bytes per launch (PMC, profiles/r01_traffic.json)"
-                    result["roofline_activation"]["algorithmic_bytes_per_launch"] = a_b / len(act_rec)
-            except (NameError, KeyError):
-                pass
+    mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
+    tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32/tokgemm"]
+    if args.dump_launches:
+        agg = {}
+        for kind, fl, nb, e0, e1, shp in rec:
+            k = (kind,) + shp
+            n, f, m = agg.get(k, (0, 0, 0.0))
+            agg[k] = (n + 1, f + fl, m + e0.elapsed_time(e1))
+        with open(args.dump_launches, "w") as fh:
+            fh.write("kind Cin Cout K dil Lout prologue rows | launches gflop ms TF/s\n")
+            for k, (n, f, m) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                fh.write(f"{k[0][4:].replace('_f32', ''):14s} {k[1]:5d} {k[2]:5d} {k[3]:3d} {k[4]:2d} {k[5]:6d} {k[6]} {k[7]} | "
+                         f"{n:4d} {f / 1e9:10.1f} {m:9.3f} {f / (m * 1e-3) / 1e12:7.2f}\n")
+    tot_ms = sum(m for _, _, m in mf)
+    tot_fl = sum(f for f, _, _ in mf)
+    tot_b = sum(b for _, b, _ in mf)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
 
-    # ---- CPU baseline: the oracle on this box's host cores, bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import hsp_oracle as O
-        # host threads: what the process may run on, capped -- torch's CPU convs stop scaling
-        # (and oversubscribe badly) far below the 256 logical CPUs of the GPU box
-        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
-        torch.set_num_threads(cores)
-        sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
-        # bounded sample: a 1-s utterance first; the 4-s one only if the budget (~25 s) allows
-        def cpu_run(frames):
-            ci_ = synth.synth_inputs(1, frames, seed=20240)
-            t_ = lambda k: torch.from_numpy(ci_[k])
-            c0 = time.perf_counter()
-            with torch.no_grad():
-                out, _ = O.synth_infer(sd, cfg, t_("mel"), t_("w2v"), t_("length"), t_("f0"), t_("noise"))
-            return time.perf_counter() - c0, ci_, out
-        cpu_run(25)                         # warm-up (thread pools, oneDNN primitives)
-        t1, ci, ro = cpu_run(50)
-        frames, times = 50, [t1]
-        if t1 * 4 * 2 < 25.0:
-            frames, times = T, []
-            while len(times) < 3 and sum(times) + (times[-1] if times else 4 * t1) < 25.0:
-                tt, ci, ro = cpu_run(T)
-                times.append(tt)
-        best = sorted(times)[len(times) // 2]
-        # parity of the GPU path on the very utterance the oracle just synthesised
+    # HBM bytes of the same kernel from the PMC counters: measured by tools/pmc_traffic.sh (rocprofv3 cannot wrap
+    # a run from inside) and committed under profiles/.  Quoted only when that profile was taken on THIS build of
+    # the library, with this workload and this launch mix; otherwise null, with the reason.
+    traffic, traffic_note, tj = None, None, None
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(path):
+        traffic_note = "no profiles/r02_traffic.json"
+    else:
+        with open(path) as fh:
+            tj = json.load(fh)
+        if tj.get("lib_sha16") != _build_id():
+            traffic_note, tj = f"profile taken on library {tj.get('lib_sha16')}, this run uses {_build_id()}", None
+        elif (tj.get("batch_per_gpu"), tj.get("frames")) != (args.batch, wl.frames):
+            traffic_note, tj = "profile taken on another workload size", None
+        elif tj.get("conv1d_mfma_launches_per_step") != len(mf) or tj.get("act1d_launches_per_step") != len(act_rec):
+            traffic_note, tj = "profile taken with another launch mix", None
+        else:
+            traffic = tj["conv1d_mfma_bytes_per_step"]["calibrated"] / len(mf)
+            traffic_note = ("HBM bytes per launch: PMC FETCH_SIZE and WRITE_SIZE (separate passes), FETCH scaled by the "
+                            "factor calibrated on a float4 copy of known size; raw / x2 / calibrated per step: "
+                            + json.dumps(tj["conv1d_mfma_bytes_per_step"]))
+    result["roofline"] = {
+        "kernel": "conv1d_mfma_kernel (all tile shapes; the 1x1 token-GEMM launches of the same entry point "
+                  "are excluded: %d launches, %.2f ms per step)" % (len(tg), sum(m for _, _, m in tg)),
+        "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+        "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
+        "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
+        "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,
+        "hbm_frac_of_8TBs": (tot_b / (tot_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+        "share_of_step_time_single_stream": tot_ms / result["ms_per_step"],
+        "timing": "one extra step, launches serialised on one stream, event pair per launch",
+    }
+    # whole-step fractions SURVEY.md 8(d) defines (Generator-only algorithmic work per audio-second over the step time)
+    audio_s = args.batch * args.seconds
+    result["roofline"]["step_fma_fraction"] = 63.3e9 * audio_s / (result["ms_per_step"] * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    result["roofline"]["step_hbm_fraction"] = 391e6 * audio_s / (result["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    if act_rec:
+        # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
+        a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)
+        a_b = sum(nb for nb, _, _ in act_rec)
+        a_gbs = a_b / (a_ms * 1e-3) / 1e9
+        result["roofline_activation"] = {
+            "kernel": "act1d_seg_kernel (hsp_act1d_snakebeta_f32)", "bound": "hbm", "achieved": a_gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_gbs / HBM_PEAK_GBS, "launches_per_step": len(act_rec),
+            "kernel_ms_per_step": a_ms, "algorithmic_mb_per_step": a_b / 1e6,
+            "algorithmic_bytes": "one fp32 read + one fp32 write per element",
+            "algorithmic_bytes_per_launch": a_b / len(act_rec),
+            "traffic": (tj["act1d_seg_bytes_per_step"]["calibrated"] / len(act_rec)) if tj else None,
+            "timing": "same pass as `roofline`",
+        }
+
+
+# ------------------------------------------------------------------------ CPU baseline
+def _cpu_model_string():
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for ln in out.splitlines():
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, wl, result):
+    """The oracle on this box's host cores, same synthetic inputs: configs[0] (1 x 1 s) and a bounded sample of
+    configs[1] (8 x 4 s instead of 32 x 4 s: SURVEY.md 8d allows the cut), plus the GPU path's error on the
+    very utterances the oracle synthesised."""
+    import numpy as np
+    import torch
+    from megatts2_hierspeechpp_amd import synth
+    from oracle import hsp_oracle as O
+    host_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # torch's CPU convs stop scaling (and oversubscribe badly) far below the 256 logical CPUs of the GPU box
+    cores = min(host_cpus, 32)
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(v) for k, v in wl.sd_np.items()}
+
+    def cpu_run(batch, frames):
+        ci_ = synth.synth_inputs(batch, frames, seed=20240)
+        t_ = lambda k: torch.from_numpy(ci_[k])
+        c0 = time.perf_counter()
         with torch.no_grad():
-            g_ = lambda k: torch.from_numpy(ci[k]).to(dev)
-            go, _ = net.infer(g_("mel"), g_("w2v"), g_("length"), g_("f0"), noise=g_("noise"))
-        result["cpu_baseline"] = {
-            "value": 320 * frames / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle synth_infer, 1 utterance x {frames / 50:g} s, median of {len(times)} runs "
-                      f"({best:.2f} s each)", "rtf": best / (frames / 50),
-            "gpu_vs_oracle_maxabs": float((go.cpu() - ro).abs().max()),
-        }
+            out, _ = O.synth_infer(sd, VOC_CFG, t_("mel"), t_("w2v"), t_("length"), t_("f0"), t_("noise"))
+        return time.perf_counter() - c0, ci_, out
 
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    def gpu_err(ci, ro):
+        with torch.no_grad():
+            g_ = lambda k: torch.from_numpy(ci[k]).to(wl.dev)
+            go, _ = wl.model.infer(g_("mel"), g_("w2v"), g_("length"), g_("f0"), noise=g_("noise"))
+        return float((go.cpu() - ro).abs().max())
+
+    cpu_run(1, 25)                          # warm-up (thread pools, oneDNN primitives)
+    t1 = []
+    for _ in range(3):
+        tt, ci1, ro1 = cpu_run(1, 50)
+        t1.append(tt)
+    m1 = float(np.median(t1))
+    # configs[1] sample: 8 x 4 s if it fits ~25 s of CPU work, else 1 x 4 s
+    est8 = m1 * 4 * 8
+    sb = 8 if est8 < 25.0 else 1
+    t8, ci8, ro8 = cpu_run(sb, wl.frames)
+    result["cpu_baseline"] = {
+        "value": sb * 320 * wl.frames / t8, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle synth_infer on {sb} x {wl.frames / 50:g} s of configs[1]'s 32 x {wl.frames / 50:g} s "
+                  f"(one run, {t8:.2f} s)", "rtf": t8 / (sb * wl.frames / 50),
+        "gpu_vs_oracle_maxabs": gpu_err(ci8, ro8),
+        "config0_1x1s": {"value": 320 * 50 / m1, "unit": "samples/s", "rtf": m1 / 1.0,
+                         "sample": f"1 utterance x 1 s, median of 3 runs ({m1:.3f} s)",
+                         "gpu_vs_oracle_maxabs": gpu_err(ci1, ro1)},
+        "host_cpus": host_cpus, "cpu_model": _cpu_model_string(),
+        "threads_note": "torch intra-op threads = min(host CPUs, 32): the oneDNN convs do not scale past that",
+    }
+
+
+# ------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_children(argv, args.gpus)
+
+    result, wl = run_bench(args, VocoderWorkload)
+    import torch.distributed as dist
+    if result is not None:
+        if not args.no_roofline:
+            vocoder_roofline(args, wl, result)
+        if result["n_gpus"] == 1 and not args.no_cpu_baseline:
+            cpu_baseline(args, wl, result)
+        if result["n_gpus"] == 1 and not args.no_extra:
+            from tools import bench_extra
+            extra = {}
+            extra["sr48_b32"] = bench_extra.sr48_b32(wl.dev, steps=5, net=wl.model)
+            del wl
+            extra["tts_b16"] = bench_extra.tts_b16(torch_device(), steps=3)
+            result["extra_configs"] = extra
+        print(json.dumps(result), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def torch_device():
+    import torch
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

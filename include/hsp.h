@@ -16,7 +16,8 @@
  *   - launchers never allocate, never synchronise, never throw; they return 0 on
  *     success, HSP_EINVAL (-1) on bad arguments, or the positive hipError_t of the launch
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream)
- *   - thread-compatible: no mutable global state
+ *   - thread-compatible: the only global state is a per-device "dynamic LDS limit raised" flag per kernel
+ *     (atomic, idempotent); the first launch of a kernel on a device must not happen inside a stream capture
  */
 #ifndef HSP_H_
 #define HSP_H_
@@ -131,8 +132,9 @@ typedef struct hsp_conv1d_args {
   int64_t res_bs, res_cs;
   int32_t accumulate;
   float post_scale;
-  int32_t debug; /* 0 in production.  Tuning aids (results are then WRONG): bit 0 = producers
-                    stage only the first chunk, bit 1 = consumers skip their MFMAs */
+  int32_t debug; /* must be 0: libhsp.so returns HSP_EINVAL otherwise.  The kernel tuning switches this word
+                    selects (skip staging / MFMAs / epilogue, force a tile shape) are compiled only into the
+                    separate libhsp_tune.so (make tune, -DHSP_TUNING), which tools/ load through HSP_LIB. */
   /* Fused input LayerNorm (1x1 token GEMMs only; any other shape is refused with HSP_EINVAL):
    * y = W LN(x) + b with LN over the Cin channels of every column.  The caller packs
    * w = W diag(gamma), bias = W beta + b and ln_c1[row] = sum_ci w[ci][row]; the kernel takes the

@@ -303,22 +303,14 @@ int mha_mfma_launch(const hsp_mha_args& a, hipStream_t stream) {
   const bool whole = lds_whole <= 160 * 1024 && (blocks <= 256 || lds_whole <= 80 * 1024 || lds_slab > 80 * 1024);
   if (!whole && lds_slab > 160 * 1024) return -1;
   if (whole) {
-    static std::atomic<int> cap{32 * 1024};
-    if (lds_whole > cap.load(std::memory_order_relaxed)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_mfma_kernel<NDB, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      cap.store(160 * 1024, std::memory_order_relaxed);
-    }
+    static hsp_lds_flags flags;
+    if (lds_whole > 32 * 1024)
+      if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_mfma_kernel<NDB, true>), 160 * 1024, flags)) return e;
     hipLaunchKernelGGL((mha_mfma_kernel<NDB, true>), dim3(blocks), dim3(256), (size_t)lds_whole, stream, a, n_qt32, sp, vp);
   } else {
-    static std::atomic<int> cap{32 * 1024};
-    if (lds_slab > cap.load(std::memory_order_relaxed)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_mfma_kernel<NDB, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      cap.store(160 * 1024, std::memory_order_relaxed);
-    }
+    static hsp_lds_flags flags;
+    if (lds_slab > 32 * 1024)
+      if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_mfma_kernel<NDB, false>), 160 * 1024, flags)) return e;
     hipLaunchKernelGGL((mha_mfma_kernel<NDB, false>), dim3(blocks), dim3(256), (size_t)lds_slab, stream, a, n_qt32, sp, 65);
   }
   return (int)hipGetLastError();
@@ -354,13 +346,9 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   const int spad = a.Tk + 1;
   const int64_t lds_bytes = ((int64_t)a.D * QT + (int64_t)QT * spad + 64 * dpad) * (int64_t)sizeof(float);
   if (lds_bytes > 160 * 1024) return HSP_EINVAL;
-  static std::atomic<int> lds_cap{32 * 1024};
-  if (lds_bytes > lds_cap.load(std::memory_order_relaxed)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    lds_cap.store(160 * 1024, std::memory_order_relaxed);
-  }
+  static hsp_lds_flags flags;
+  if (lds_bytes > 32 * 1024)
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_kernel), 160 * 1024, flags)) return e;
   const int64_t blocks = (int64_t)n_qt * a.H * a.B;
   hipLaunchKernelGGL(mha_kernel, dim3((unsigned)blocks), dim3(ATT_THREADS), (size_t)lds_bytes,
                      static_cast<hipStream_t>(stream), a, n_qt, dpad, spad);

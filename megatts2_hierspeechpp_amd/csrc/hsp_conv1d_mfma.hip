@@ -1,700 +1,20 @@
-// Fused Conv1d / ConvTranspose1d as an implicit GEMM on the fp32-input matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain, same 157 TFLOP/s peak as
-// the fp32 vector pipe -- MI355X_MICROARCH.md "Matrix cores").
-//
-//   acc[m, t] = sum_j sum_ci W[j][ci][m] * xin[ci, t + j*dil - pad]
-//
-// GEMM view: M = packed output rows, N = time, K = (taps x input channels).
-// One workgroup owns a BM x BN output tile of one utterance and walks the input
-// channels in chunks of KC.  Its waves are SPECIALISED:
-//
-//   waves 0-3   "consumers": each owns a (TM x TN) grid of 32x32 MFMA blocks and does
-//               nothing but read A (weights) / B (shifted input window) fragments from
-//               LDS -- one k-step ahead of the MFMAs that use them -- and issue MFMAs;
-//   waves 4..   "producers": stage the NEXT chunk into the other half of a double
-//               buffer -- the weight slab Ws[K][KC][BM] and the input window
-//               Xa[KC][BN + (K-1)*dil] -- applying the PROLOGUE on the way: nothing,
-//               leaky-ReLU, or the whole anti-aliased SnakeBeta activation (2x polyphase
-//               up-sample -> snake -> 2x low-pass down-sample, replicate-padded at the
-//               sequence ends exactly like alias_free_torch).  Each producer wave owns
-//               whole channel rows, so the activation phases need only wave-local
-//               ordering, and the activated tensor never exists in HBM.
-//               Global loads are issued one chunk AHEAD into registers (issue early /
-//               commit late), so their latency is covered by a whole chunk of MFMAs.
-//
-// Wave w and wave w+4 share a SIMD, so the producers' VALU/LDS/global work fills the
-// issue slots between the consumers' 64-cycle MFMAs; the only workgroup-wide
-// synchronisation is one barrier per chunk.  The EPILOGUE (bias, conditioning bias,
-// gate / pointwise function, masks, per-channel scale, residual, running accumulation,
-// ConvTranspose phase shuffle) runs on the accumulator registers of the consumers.
+// hsp_conv1d_mfma_f32: argument validation and the choice of kernel, tile shape and epilogue kind.
+// The kernel itself is the template in hsp_conv1d_mfma_kernel.h, instantiated per tile shape by
+// hsp_conv1d_tile.hip; 1x1 convs over short column axes go to the token GEMM (hsp_tokgemm.hip).
 //
 // Reference call sites: see include/hsp.h (hsp_conv1d_args).
-#include <atomic>
-#include <type_traits>
-#include "hsp_device.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "hsp_conv1d_mfma_kernel.h"
 
 int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);  // hsp_tokgemm.hip; -1 = shape not taken
 
 namespace {
-
-template <int WM, int WN, int TM, int TN, int NPW_, int MINW_>
-struct Cfg {
-  static constexpr int NCW = WM * WN;              // consumer waves (4, or 8 = two per SIMD)
-  static constexpr int kWM = WM, kWN = WN, kTM = TM, kTN = TN;
-  static constexpr int BM = WM * TM * 32;
-  static constexpr int BN = WN * TN * 32;
-  static constexpr int NPW = NPW_;                 // producer waves
-  static constexpr int NPT = NPW_ * 64;            // producer threads
-  static constexpr int THREADS = 64 * (WM * WN + NPW_);
-  static constexpr int MINW = MINW_;               // waves per SIMD the register allocation must allow
-};
-
-struct LdsPlan {
-  int kc, lkc;  // chunk depth (power of two) and its log2
-  int rpw;      // channel rows per producer wave and chunk
-  int xw;       // activated window width  = BN + (K-1)*dil
-  int xwp;      // its LDS row pitch (multiple of 64: DMA instructions never straddle rows)
-  int xrw;      // raw window width        = xw + 10        (ACT1D)
-  int xrwp;     // raw row pitch in the producer scratch (multiple of 64)
-  int a2w;      // 2x-rate window width    = 2*xw + 10      (ACT1D)
-  int ws_sz, xa_sz, scr_sz;  // floats: one weight slab, one window buffer, one producer scratch
-  int xa_off, scr_off, total;
-};
-
-template <class C>
-__host__ __device__ inline LdsPlan make_plan(int K, int dil, int prologue, int lkc) {
-  LdsPlan p;
-  p.lkc = lkc;
-  p.kc = 1 << lkc;
-  p.rpw = (p.kc + C::NPW - 1) / C::NPW;
-  p.xw = C::BN + (K - 1) * dil;
-  p.xwp = (p.xw + 3 + 63) & ~63;  // +3: the 16-B window DMA starts at the aligned position below p0
-  p.xrw = p.xw + 10;
-  p.xrwp = (p.xrw + 63) & ~63;
-  p.a2w = 2 * p.xw + 10;
-  p.ws_sz = K * p.kc * C::BM;
-  p.xa_sz = p.kc * p.xwp;
-  // scratch of one producer wave: double-buffered raw rows + one 2x-rate row
-  p.scr_sz = prologue == HSP_PRO_ACT1D ? 2 * p.rpw * p.xrwp + ((p.a2w + 3) & ~3) : 0;
-  p.xa_off = 2 * p.ws_sz;
-  p.scr_off = p.xa_off + 2 * p.xa_sz;
-  p.total = p.scr_off + C::NPW * p.scr_sz;
-  return p;
-}
-
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-// workgroup barrier that does NOT drain outstanding global loads: only this wave's LDS
-// traffic has to be complete before the other role touches the buffer (__syncthreads()
-// would add s_waitcnt vmcnt(0) and expose the latency of the prefetched chunk)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// 32-bit LDS byte address of a pointer into the workgroup's dynamic shared memory
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
-}
-
-// N fragment registers from consecutive 32-float blocks: f[i] = lds[addr + i * 128 B]
-template <int N, int I = 0>
-__device__ __forceinline__ void ds_read_frags(float (&f)[N], unsigned addr) {
-  if constexpr (I < N) {
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[I]) : "v"(addr), "n"(I * 128));
-    ds_read_frags<N, I + 1>(f, addr);
-  }
-}
-
-// wave-local LDS ordering: all earlier LDS ops of this wave are complete and the
-// compiler may not move memory accesses across this point
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// ------------------------------------------------------------------- producer side
-// Only the fields the producers touch, held by value (a reference to the by-value kernel
-// argument inside an aggregate makes the compiler spill the whole struct to scratch).
-struct ProdArgs {
-  const float* w;
-  const float* zeros;      // >= 16 B of zeros: source of every out-of-range DMA lane
-  const float* alpha_exp;
-  const float* beta_inv;
-  const float* filt;
-  int K, Cin, Lin, M, w_ld, x_cs, x_ts, prologue;
-  float slope;
-};
-
-// LDS-DMA (global_load_lds): each lane supplies a global address, the data lands at
-// lds_base + lane * BYTES with no register staging; counted in vmcnt like a load.
-#define HSP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define HSP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
-__device__ __forceinline__ void dma16(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds(HSP_GPTR(g), HSP_LPTR(l), 16, 0, 0);
-}
-__device__ __forceinline__ void dma4(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds(HSP_GPTR(g), HSP_LPTR(l), 4, 0, 0);
-}
-__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <class C>
-struct Prod {
-  static constexpr int CPR = C::BM / 4;                       // float4 columns per slab row
-  static constexpr int RPI = (64 / CPR) > 0 ? (64 / CPR) : 1;  // slab rows per DMA instruction
-
-  // ---- weight slab of chunk c0 -> Ws[j][kc][BM]: rows (j, c0+kc) of the packed matrix
-  static __device__ __forceinline__ void dma_w(const ProdArgs& a, const LdsPlan& P, float* Ws, int c0, int m0, int pw,
-                                               int lane) {
-    const int r_in = lane / CPR, col = (lane % CPR) * 4;
-    const int lipj = P.lkc - __builtin_ctz(RPI);  // log2(instructions per tap); KC >= RPI
-    const int ninstr = a.K << lipj;
-    const bool colok = m0 + col < a.M;
-    const float* wcol = a.w + m0 + col;
-    for (int q = pw; q < ninstr; q += C::NPW) {
-      const int j = q >> lipj, g = q & ((1 << lipj) - 1);
-      const int ci = c0 + g * RPI + r_in;
-      const float* src = (colok && ci < a.Cin) ? wcol + (j * a.Cin + ci) * a.w_ld : a.zeros;
-      dma16(src, Ws + ((j << P.lkc) + g * RPI) * C::BM);
-    }
-  }
-
-  // ---- plain window rows -> Xa[kc][xwp] (zero outside [0, Lin) and beyond Cin)
-  static __device__ __forceinline__ void dma_x(const ProdArgs& a, const LdsPlan& P, float* Xa, const float* xb, int c0,
-                                               int p0, int pw, int lane) {
-    const int npr = P.xwp >> 6;
-    for (int kc = pw; kc < P.kc; kc += C::NPW) {
-      const int ci = c0 + kc;
-      const float* xc = xb + ci * a.x_cs;
-      for (int i = 0; i < npr; ++i) {
-        const int p = p0 + lane + 64 * i;
-        const float* src = (ci < a.Cin && p >= 0 && p < a.Lin) ? xc + p * a.x_ts : a.zeros;
-        dma4(src, Xa + kc * P.xwp + 64 * i);
-      }
-    }
-  }
-  // same with 16-B lanes: the window starts at p0a = p0 rounded down to a multiple of 4 and the
-  // tensor is 16-B addressable with Lin % 4 == 0, so every 4-group is fully inside or outside
-  static __device__ __forceinline__ void dma_x16(const ProdArgs& a, const LdsPlan& P, float* Xa, const float* xb,
-                                                 int c0, int p0a, int pw, int lane) {
-    const int ngrp = (P.xw + 3 + 3) >> 2;
-    for (int kc = pw; kc < P.kc; kc += C::NPW) {
-      const int ci = c0 + kc;
-      const float* xc = xb + ci * a.x_cs;
-      for (int g0 = 0; g0 < ngrp; g0 += 64) {
-        const int g = g0 + lane, p = p0a + 4 * g;
-        if (g < ngrp) {
-          const float* src = (ci < a.Cin && p >= 0 && p < a.Lin) ? xc + p : a.zeros;
-          dma16(src, Xa + kc * P.xwp + 4 * g0);
-        }
-      }
-    }
-  }
-  static __device__ __forceinline__ void lrelu_x(const ProdArgs& a, const LdsPlan& P, float* Xa, int pw, int lane) {
-    for (int kc = pw; kc < P.kc; kc += C::NPW)
-      for (int s = lane; s < P.xwp; s += 64) {
-        const float v = Xa[kc * P.xwp + s];
-        Xa[kc * P.xwp + s] = v > 0.0f ? v : v * a.slope;
-      }
-  }
-
-  // ---- ACT1D: raw rows (replicate padding = index clamp) -> this wave's scratch
-  static __device__ __forceinline__ void dma_raw(const ProdArgs& a, const LdsPlan& P, float* rawbuf, const float* xb,
-                                                 int c0, int p0, int pw, int lane) {
-    const int npr = P.xrwp >> 6;
-    for (int rs = 0; rs < P.rpw; ++rs) {
-      const int ci = c0 + pw + rs * C::NPW;
-      const float* xc = xb + ci * a.x_cs;
-      for (int i = 0; i < npr; ++i) {
-        const float* src = ci < a.Cin ? xc + hsp_clampi(p0 - 5 + lane + 64 * i, 0, a.Lin - 1) : a.zeros;
-        dma4(src, rawbuf + rs * P.xrwp + 64 * i);
-      }
-    }
-  }
-
-  // one channel row: raw (LDS) -> 2x-rate snake signal (LDS) -> activated window row.
-  // VALU cycles here are stolen from the fp32 MFMAs of the consumer wave on the same SIMD
-  // (they share the fp32 datapath), so the arithmetic is kept minimal: packed fp32 FMAs
-  // (v_pk_fma_f32: an even and an odd output sample per lane) and hardware cosine.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  static __device__ __forceinline__ void act_row(const ProdArgs& a, const LdsPlan& P, const float* raw, float* a2,
-                                                 float* xa, int ci, int p0, int lane) {
-    const int L = a.Lin;
-    const int mlo = 2 * p0 - 5;
-    const bool interior = mlo >= 0 && mlo + P.a2w <= 2 * L;  // no index clamp needed at the 2x rate
-    const float* hu = a.filt;
-    const float* hd = a.filt + 12;
-    const int cic = ci < a.Cin ? ci : a.Cin - 1;
-    const float kf = a.alpha_exp[cic] * 0.318309886183790672f, kb = 0.5f * a.beta_inv[cic];
-    // phase B: a[m] = snake(2 * up[m]);  up[2q]   = sum_i x[q-3+i] * hu[11-2i],
-    //                                    up[2q+1] = sum_i x[q-2+i] * hu[10-2i]   (i = 0..5)
-    if (interior) {
-      // slot 2i+1 <-> m = 2q (q = p0-2+i), slot 2i+2 <-> m = 2q+1: both read raw[i .. i+6]
-      const int npair = (P.a2w - 1) >> 1;
-      for (int i = lane; i < npair; i += 64) {
-        float xv[7];
-#pragma unroll
-        for (int t = 0; t < 7; ++t) xv[t] = raw[i + t];
-        f32x2 u = {0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          const f32x2 xx = {xv[t], xv[t + 1]};
-          const f32x2 hh = {hu[11 - 2 * t], hu[10 - 2 * t]};
-          u = __builtin_elementwise_fma(xx, hh, u);
-        }
-        u = u * 2.0f;
-        a2[2 * i + 1] = hsp_snake_hw(u.x, kf, kb);
-        a2[2 * i + 2] = hsp_snake_hw(u.y, kf, kb);
-      }
-      if (lane < 2) {  // slot 0 (odd m, q = p0-3, raw[0..5]) and the last slot (even m, raw[xw+4..xw+9])
-        const float* xr_ = lane ? raw + P.xw + 4 : raw;
-        float uu = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) uu = fmaf(xr_[t], lane ? hu[11 - 2 * t] : hu[10 - 2 * t], uu);
-        a2[lane ? P.a2w - 1 : 0] = hsp_snake_hw(2.0f * uu, kf, kb);
-      }
-    } else {
-      for (int s = lane; s < P.a2w; s += 64) {
-        const int m = hsp_clampi(mlo + s, 0, 2 * L - 1);
-        const int q = m >> 1, odd = m & 1;
-        const float* xr_ = raw + (q - 3 + odd) - (p0 - 5);
-        float u = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) u = fmaf(xr_[t], odd ? hu[10 - 2 * t] : hu[11 - 2 * t], u);
-        a2[s] = hsp_snake_hw(2.0f * u, kf, kb);
-      }
-    }
-    wave_lds_fence();
-    // phase C: y[p] = sum_k hd[k] * a[clamp(2p+k-5)], zero outside [0, L) (conv zero padding)
-    for (int s = lane; s < P.xwp; s += 64) {
-      const int p = p0 + s;
-      f32x2 v = {0.0f, 0.0f};
-      if (p >= 0 && p < L && s < P.xw) {
-        const f32x2* ar = reinterpret_cast<const f32x2*>(a2 + 2 * s);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const f32x2 hh = {hd[2 * k], hd[2 * k + 1]};
-          v = __builtin_elementwise_fma(ar[k], hh, v);
-        }
-      }
-      xa[s] = v.x + v.y;
-    }
-    wave_lds_fence();  // a2 is reused by the next row
-  }
-
-  static __device__ __forceinline__ void act_rows(const ProdArgs& a, const LdsPlan& P, const float* rawbuf, float* a2,
-                                                  float* Xa, int c0, int p0, int pw, int lane) {
-    for (int rs = 0; rs < P.rpw; ++rs) {
-      const int row = pw + rs * C::NPW;
-      if (row < P.kc) act_row(a, P, rawbuf + rs * P.xrwp, a2, Xa + row * P.xwp, c0 + row, p0, lane);
-    }
-  }
-};
-
-// ------------------------------------------------------------------------ kernel
-template <class C>
-__global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
-                                                                 const int n_nt, const int lkc,
-                                                                 const int epi_vec, const int xvec) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int BM = C::BM, BN = C::BN, TM = C::kTM, TN = C::kTN;
-  const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
-  const int KC = P.kc;
-
-  // blockIdx.x = mt + n_mt * (nt + n_nt * b): row tiles fastest, so the blocks that
-  // round-robin onto one XCD keep hitting the same weight slab in that XCD's L2.
-  int bid = blockIdx.x;
-  const int mt = bid % n_mt;
-  bid /= n_mt;
-  const int nt = bid % n_nt;
-  const int b = bid / n_nt;
-  const int m0 = mt * BM, t0 = nt * BN;
-  const int p0 = t0 - a.pad;  // first activated-input position of the window
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int nchunks = (a.Cin + KC - 1) >> lkc;
-
-  if (wave >= C::NCW) {
-    // ------------------------------------------------------------ producers
-    const int pw = wave - C::NCW;
-    const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
-                      (int)a.x_ts, a.prologue, a.slope};
-    const float* xb = a.x + (int64_t)b * a.x_bs;
-    using PR = Prod<C>;
-    float* const Ws0 = lds;
-    float* const Xa0 = lds + P.xa_off;
-    if (a.prologue != HSP_PRO_ACT1D) {
-      const int p0a = p0 & ~3;
-      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
-      if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
-      wait_vm0();
-      if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
-      lds_barrier();
-      for (int c = 0; c < nchunks; ++c) {
-        const int nb = (c + 1) & 1;
-        if (c + 1 < nchunks && !(a.debug & 1)) {
-          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
-          if (xvec) PR::dma_x16(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0a, pw, lane);
-          else PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
-          wait_vm0();
-          if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
-        }
-        lds_barrier();
-      }
-    } else {
-      float* const scr = lds + P.scr_off + pw * P.scr_sz;   // raw[2][rpw][xrwp], a2[a2w]
-      float* const a2 = scr + 2 * P.rpw * P.xrwp;
-      const int rsz = P.rpw * P.xrwp;
-      PR::dma_raw(pa, P, scr, xb, 0, p0, pw, lane);
-      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
-      wait_vm0();
-      PR::act_rows(pa, P, scr, a2, Xa0, 0, p0, pw, lane);
-      if (nchunks > 1) PR::dma_raw(pa, P, scr + rsz, xb, KC, p0, pw, lane);
-      wait_vm0();
-      lds_barrier();
-      for (int c = 0; c < nchunks; ++c) {
-        const int nb = (c + 1) & 1;
-        if (c + 1 < nchunks && !(a.debug & 1)) {
-          if (!(a.debug & 8)) PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
-          if (c + 2 < nchunks) PR::dma_raw(pa, P, scr + (c & 1) * rsz, xb, (c + 2) << lkc, p0, pw, lane);
-          if (!(a.debug & 4)) PR::act_rows(pa, P, scr + nb * rsz, a2, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0, pw, lane);
-          wait_vm0();
-        }
-        lds_barrier();
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------- consumers
-  const int wm = wave / C::kWN, wn = wave % C::kWN;
-  const int l32 = lane & 31, half = lane >> 5;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const int wlane = half * BM + wm * (TM * 32) + l32;
-  const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? (p0 & 3) : 0);
-  const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4
-  const int a_step = KC * BM;          // next tap, same channel pair
-
-  lds_barrier();  // chunk 0 staged
-  for (int c = 0; c < nchunks; ++c) {
-    const int cb = c & 1;
-    const float* const ws = lds + cb * P.ws_sz + wlane;
-    const float* const xs = lds + P.xa_off + cb * P.xa_sz + xlane;
-    // k-steps ordered channel-pair outer, tap inner; the (tap, pair) -> LDS offset walk is
-    // scalar.  Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of
-    // step s+1 are issued right after the wait that retires the reads of step s and BEFORE
-    // the 8..16 MFMAs of step s, so an LDS round trip never sits between two MFMA groups
-    // (left to itself hipcc sinks the prefetch under the MFMAs and waits on it at once).
-    int offA = 0, offB = 0, j = 0, kk = 0;
-    auto advance = [&]() __attribute__((always_inline)) {
-      const bool wrap = (j + 1 == a.K);
-      kk += wrap ? 1 : 0;
-      j = wrap ? 0 : j + 1;
-      offA = wrap ? 2 * kk * BM : offA + a_step;
-      offB = wrap ? 2 * kk * P.xwp : offB + a.dil;
-    };
-    const unsigned aA = lds_addr(ws), aB = lds_addr(xs);  // per-lane LDS byte addresses
-    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto read_set = [&](float (&fa)[TM], float (&fb)[TN], unsigned va, unsigned vb) __attribute__((always_inline)) {
-      ds_read_frags<TM>(fa, va);
-      ds_read_frags<TN>(fb, vb);
-    };
-    auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
-    };
-    read_set(fa0, fb0, aA, aB);
-    for (int s = (a.debug & 2) ? nsteps : 0; s < nsteps; s += 2) {
-      advance();  // step s+1 (always valid: nsteps is even)
-      unsigned va = aA + 4u * (unsigned)offA, vb = aB + 4u * (unsigned)offB;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
-      __builtin_amdgcn_sched_barrier(0);
-      read_set(fa1, fb1, va, vb);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
-      mma_set(fa0, fb0);
-      advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
-      const bool more = s + 2 < nsteps;
-      va = aA + 4u * (unsigned)(more ? offA : 0);
-      vb = aB + 4u * (unsigned)(more ? offB : 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
-      __builtin_amdgcn_sched_barrier(0);
-      read_set(fa0, fb0, va, vb);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_set(fa1, fb1);
-    }
-    lds_barrier();
-  }
-
-  // ---- epilogue.  C/D map of the 32x32 forms: col = lane & 31,
-  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  // static_for keeps every accumulator index a compile-time constant: a runtime index
-  // into acc[][] would demote the whole accumulator file to scratch memory.
-  if (a.debug & 16) return;
-  const int mw = m0 + wm * (TM * 32);
-  const int tw = t0 + wn * (TN * 32) + l32;
-  if (epi_vec) {
-    // Vector epilogue (plain rows, 16-B aligned tensors): each 32x32 accumulator block is
-    // transposed through this wave's LDS staging area (the weight buffers are free after the
-    // last barrier) so that a lane owns 4 consecutive time steps of 4 rows -> float4 residual /
-    // accumulate loads and float4 stores.  The common case (no pointwise function, mask or
-    // per-channel scale: every AMP / ConvTranspose-free conv of the generator) gets a branch-
-    // and spill-free body; a scratch reload or a late constant load inside this loop would
-    // wait on vmcnt, which also drains every older store.
-    constexpr int ESTR = 36;
-    float* const stage = lds + wave * (32 * ESTR);
-    const int er = lane >> 3, ec = (lane & 7) * 4;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto run = [&](auto fast_tag) __attribute__((always_inline)) {
-      constexpr bool FAST = decltype(fast_tag)::value;
-      static_for<TM>([&](auto ii) __attribute__((always_inline)) {
-        constexpr int i = decltype(ii)::value;
-        float add[4], cs[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = mw + i * 32 + er + 8 * q;
-          add[q] = 0.0f;
-          cs[q] = a.scale;
-          if (co < a.Cout) {
-            if (a.bias) add[q] = a.bias[co];
-            if constexpr (!FAST) {
-              if (a.cbias) add[q] += a.cbias[(int64_t)b * a.cbias_bs + co];
-              if (a.cscale) cs[q] *= a.cscale[(int64_t)b * a.cscale_bs + co];
-            }
-          }
-        }
-        static_for<TN>([&](auto nn) __attribute__((always_inline)) {
-          constexpr int n = decltype(nn)::value;
-          const int t = t0 + wn * (TN * 32) + n * 32 + ec;
-          const bool tok = t < a.ncols;
-          float4 rs[4], yo[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int co = mw + i * 32 + er + 8 * q;
-            const bool ok = tok && co < a.Cout;
-            rs[q] = z4;
-            yo[q] = z4;
-            if (ok && a.res) rs[q] = *reinterpret_cast<const float4*>(a.res + (int64_t)b * a.res_bs + (int64_t)co * a.res_cs + t);
-            if (ok && a.accumulate) yo[q] = *reinterpret_cast<const float4*>(a.y + (int64_t)b * a.y_bs + (int64_t)co * a.y_cs + t);
-          }
-          float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-          if constexpr (!FAST) {
-            if (a.mask_mode != HSP_MASK_NONE && tok) mk = *reinterpret_cast<const float4*>(a.mask + (int64_t)b * a.mask_bs + t);
-          }
-          static_for<16>([&](auto rr) __attribute__((always_inline)) {
-            constexpr int r = decltype(rr)::value;
-            stage[((r & 3) + 8 * (r >> 2) + 4 * half) * ESTR + l32] = acc[i][n][r];
-          });
-          wave_lds_fence();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int co = mw + i * 32 + er + 8 * q;
-            if (tok && co < a.Cout) {
-              const float4 v = *reinterpret_cast<const float4*>(stage + (er + 8 * q) * ESTR + ec);
-              float e[4] = {v.x, v.y, v.z, v.w};
-              const float r4[4] = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
-              const float y4[4] = {yo[q].x, yo[q].y, yo[q].z, yo[q].w};
-              const float m4[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                float x = e[u] + add[q];
-                if constexpr (!FAST) {
-                  x = hsp_apply_act(x, a.act);
-                  if (a.mask_mode & HSP_MASK_PRE) x *= m4[u];
-                }
-                x = fmaf(x, cs[q], r4[u]);
-                if constexpr (!FAST) {
-                  if (a.mask_mode & HSP_MASK_POST) x *= m4[u];
-                }
-                e[u] = (x + y4[u]) * a.post_scale;
-              }
-              *reinterpret_cast<float4*>(a.y + (int64_t)b * a.y_bs + (int64_t)co * a.y_cs + t) =
-                  make_float4(e[0], e[1], e[2], e[3]);
-            }
-          }
-          wave_lds_fence();  // the staging area is rewritten by the next block
-        });
-      });
-    };
-    if (a.act == HSP_ACT_NONE && a.mask_mode == HSP_MASK_NONE && !a.cscale && !a.cbias) run(std::true_type{});
-    else run(std::false_type{});
-    return;
-  }
-  if (a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU) {
-    if constexpr (TM % 2 == 0) {
-      const int H = a.gate_half;
-      static_for<TM / 2>([&](auto ih) __attribute__((always_inline)) {
-        constexpr int i = 2 * decltype(ih)::value;
-        const int mpair = mw + i * 32;  // packed row of the 'a' block; multiple of 64
-        static_for<TN>([&](auto nn) __attribute__((always_inline)) {
-          constexpr int n = decltype(nn)::value;
-          const int t = tw + n * 32;
-          if (mpair < a.M && t < a.ncols) {
-            static_for<16>([&](auto rr) __attribute__((always_inline)) {
-              constexpr int r = decltype(rr)::value;
-              const int co = (mpair >> 6) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (co < H) {
-                float va = acc[i][n][r], vb = acc[i + 1][n][r];
-                if (a.bias) { va += a.bias[co]; vb += a.bias[H + co]; }
-                if (a.cbias) {
-                  va += a.cbias[(int64_t)b * a.cbias_bs + co];
-                  vb += a.cbias[(int64_t)b * a.cbias_bs + H + co];
-                }
-                const float v = (a.rows == HSP_ROWS_GATE_WN ? hsp_tanh(va) : va) * hsp_sigmoid(vb);
-                hsp_epilogue_store(a, b, co, t, v);
-              }
-            });
-          }
-        });
-      });
-    }
-  } else if (a.rows == HSP_ROWS_SHUFFLE && a.act == HSP_ACT_NONE && a.mask_mode == HSP_MASK_NONE && !a.cscale &&
-             !a.cbias && !a.res && !a.accumulate) {
-    // ConvTranspose fast path: row m = co*up + phase writes y[co, up*t + phase - pad].  Row
-    // constants (channel, phase, bias, row pointer) are resolved once per accumulator row; the
-    // store loop has no loads, so nothing ever waits on vmcnt.  The `up` stores of one channel
-    // (registers r&3 for up = 4, r&1 for up = 2) interleave into full lines in L2.
-    const float up_inv = 1.0f / (float)a.up;
-    static_for<TM>([&](auto ii) __attribute__((always_inline)) {
-      constexpr int i = decltype(ii)::value;
-      float* yrow[16];
-      float bz[16];
-      int toff[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int co = (int)(((float)m + 0.5f) * up_inv);
-        const bool ok = m < a.M && co < a.Cout;
-        toff[r] = ok ? (m - co * a.up) - a.shuf_pad : -(1 << 30);
-        yrow[r] = a.y + (int64_t)b * a.y_bs + (int64_t)(ok ? co : 0) * a.y_cs;
-        bz[r] = (ok && a.bias) ? a.bias[co] : 0.0f;
-      }
-      static_for<TN>([&](auto nn) __attribute__((always_inline)) {
-        constexpr int n = decltype(nn)::value;
-        const int t = tw + n * 32;
-        if (t < a.ncols) {
-          static_for<16>([&](auto rr) __attribute__((always_inline)) {
-            constexpr int r = decltype(rr)::value;
-            const int to = a.up * t + toff[r];
-            if (to >= 0 && to < a.Lout) yrow[r][to] = (acc[i][n][r] + bz[r]) * a.scale * a.post_scale;
-          });
-        }
-      });
-    });
-  } else {
-    const float up_inv = a.rows == HSP_ROWS_SHUFFLE ? 1.0f / (float)a.up : 1.0f;
-    static_for<TM>([&](auto ii) __attribute__((always_inline)) {
-      constexpr int i = decltype(ii)::value;
-      static_for<TN>([&](auto nn) __attribute__((always_inline)) {
-        constexpr int n = decltype(nn)::value;
-        const int t = tw + n * 32;
-        if (t < a.ncols) {
-          static_for<16>([&](auto rr) __attribute__((always_inline)) {
-            constexpr int r = decltype(rr)::value;
-            const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            int co = m, to = t;
-            bool ok = m < a.M;
-            if (a.rows == HSP_ROWS_SHUFFLE) {
-              co = (int)(((float)m + 0.5f) * up_inv);  // m / up, exact for m < 2^22 (no integer divide)
-              to = a.up * t + (m - co * a.up) - a.shuf_pad;
-              ok = ok && to >= 0 && to < a.Lout;
-            }
-            ok = ok && co < a.Cout;
-            if (ok) {
-              float v = acc[i][n][r];
-              if (a.bias) v += a.bias[co];
-              if (a.cbias) v += a.cbias[(int64_t)b * a.cbias_bs + co];
-              v = hsp_apply_act(v, a.act);
-              hsp_epilogue_store(a, b, co, to, v);
-            }
-          });
-        }
-      });
-    });
-  }
-}
-
-// -------------------------------------------------------------------- host side
-constexpr int kMaxLdsBytes = 160 * 1024;
-constexpr int kLdsTarget = 80 * 1024;  // two workgroups per CU when possible
-
-// largest chunk depth (log2) this tile shape can stage for the launch, or -1
-template <class C>
-int pick_lkc(const hsp_conv1d_args& a, int lds_limit) {
-  const bool act = a.prologue == HSP_PRO_ACT1D;
-  int cin_p2 = 2;
-  while ((1 << cin_p2) < a.Cin && cin_p2 < 6) ++cin_p2;  // no point staging past Cin
-  for (int lkc = cin_p2; lkc >= 2; --lkc) {
-    const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
-    if (P.total * (int)sizeof(float) > lds_limit) continue;
-    if (P.kc < Prod<C>::RPI) continue;   // a weight DMA instruction must stay inside one tap
-    if (act && P.rpw > 2) continue;      // activation work per producer wave and chunk
-    return lkc;
-  }
-  return -1;
-}
-
-template <class C>
-int launch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
-  // a shape whose register budget admits two workgroups per CU keeps its LDS under half the
-  // CU's; the others take the deepest chunk the whole 160 KB can stage (fewer barriers, and the
-  // DMA of a chunk gets a longer MFMA phase to land under)
-  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS;
-  int lkc = pick_lkc<C>(a, two_per_cu ? kLdsTarget : kMaxLdsBytes);
-  if (lkc < 0) lkc = pick_lkc<C>(a, kMaxLdsBytes);
-  if (lkc < 0) return HSP_EINVAL;
-  int lds_bytes = make_plan<C>(a.K, a.dil, a.prologue, lkc).total * (int)sizeof(float);
-  if (plan_out) {
-    plan_out[0] = C::BM; plan_out[1] = C::BN; plan_out[2] = 1 << lkc; plan_out[3] = lds_bytes;
-    return 0;
-  }
-  const int n_mt = (a.M + C::BM - 1) / C::BM;
-  const int n_nt = (a.ncols + C::BN - 1) / C::BN;
-  const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
-  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
-  auto kern = conv1d_mfma_kernel<C>;
-  // raise the kernel's dynamic-LDS cap once (idempotent; kept out of the launch path
-  // afterwards so that launches are legal inside a hipGraph stream capture)
-  static std::atomic<int> lds_cap{32 * 1024};
-  if (lds_bytes > lds_cap.load(std::memory_order_relaxed)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    lds_cap.store(kMaxLdsBytes, std::memory_order_relaxed);
-  }
-  // vector epilogue: plain rows and every tensor it touches 16-B addressable in float4 steps
-  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const bool epi_vec = a.rows == HSP_ROWS_PLAIN && (a.ncols & 3) == 0 && al16(a.y) && (a.y_bs & 3) == 0 &&
-                       (a.y_cs & 3) == 0 &&
-                       (!a.res || (al16(a.res) && (a.res_bs & 3) == 0 && (a.res_cs & 3) == 0)) &&
-                       (a.mask_mode == HSP_MASK_NONE || (al16(a.mask) && (a.mask_bs & 3) == 0)) && !(a.debug & 32);
-  if (lds_bytes < C::NCW * 32 * 36 * 4) lds_bytes = C::NCW * 32 * 36 * 4;  // epilogue staging area
-  // 16-B window DMA: plain prologue on a 16-B addressable input whose length is a multiple of 4
-  const bool xvec = a.prologue != HSP_PRO_ACT1D && a.x_ts == 1 && (a.Lin & 3) == 0 && (a.x_cs & 3) == 0 &&
-                    (a.x_bs & 3) == 0 && al16(a.x) && !(a.debug & 64);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc,
-                     epi_vec ? 1 : 0, xvec ? 1 : 0);
-  return (int)hipGetLastError();
-}
+using namespace hspconv;
 
 int validate(const hsp_conv1d_args& a) {
   if (!a.x || !a.w || !a.y) return HSP_EINVAL;
+#ifndef HSP_TUNING
+  if (a.debug != 0) return HSP_EINVAL;  // tuning switches exist only in libhsp_tune.so
+#endif
   if (a.B <= 0 || a.Cin <= 0 || a.Lin <= 0 || a.K <= 0 || a.M <= 0 || a.Cout <= 0 || a.Lout <= 0 || a.ncols <= 0)
     return HSP_EINVAL;
   if (a.stride != 1 || (a.M & 3) || (a.w_ld & 3) || a.w_ld < a.M || a.dil < 1) return HSP_EINVAL;
@@ -702,12 +22,15 @@ int validate(const hsp_conv1d_args& a) {
   // the kernel indexes one utterance / the weight matrix with 32-bit element offsets
   if ((int64_t)a.K * a.Cin * a.w_ld >= (1ll << 31)) return HSP_EINVAL;
   if ((int64_t)a.Cin * a.x_cs + (int64_t)a.Lin * a.x_ts >= (1ll << 31) || a.x_cs < 0 || a.x_ts < 0) return HSP_EINVAL;
+  if (a.y_cs < 0 || (int64_t)a.Cout * a.y_cs + a.Lout >= (1ll << 31)) return HSP_EINVAL;
+  if (a.res && (a.res_cs < 0 || (int64_t)a.Cout * a.res_cs + a.Lout >= (1ll << 31))) return HSP_EINVAL;
   if (a.prologue == HSP_PRO_ACT1D && (!a.alpha_exp || !a.beta_inv || !a.filt || a.x_ts != 1)) return HSP_EINVAL;
   if (!a.zeros || (reinterpret_cast<uintptr_t>(a.zeros) & 15) != 0) return HSP_EINVAL;
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_ACT1D) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
   if (a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU) {
     if (a.gate_half <= 0 || (a.gate_half & 31) || a.M != 2 * a.gate_half || a.Cout != a.gate_half) return HSP_EINVAL;
+    if (a.prologue == HSP_PRO_ACT1D) return HSP_EINVAL;
   } else if (a.rows == HSP_ROWS_SHUFFLE) {
     if (a.up <= 0 || a.up > 16 || a.M != a.Cout * a.up || a.M > (1 << 16)) return HSP_EINVAL;
   } else if (a.rows != HSP_ROWS_PLAIN) {
@@ -716,56 +39,39 @@ int validate(const hsp_conv1d_args& a) {
   return 0;
 }
 
-// tile shapes <WM, WN, TM, TN, producer waves, min waves per SIMD>
-using M256 = Cfg<2, 2, 4, 2, 4, 2>;    // 256 x 128, one workgroup per CU
-using M128 = Cfg<2, 2, 2, 2, 4, 4>;    // 128 x 128, two workgroups per CU
-using M64 = Cfg<1, 4, 2, 2, 8, 3>;     //  64 x 256
-using M32 = Cfg<1, 4, 1, 4, 8, 3>;     //  32 x 512
-using M64P = Cfg<1, 4, 2, 2, 4, 4>;    //  64 x 256, plain prologue: four producer waves, two workgroups per CU
-using M32P = Cfg<1, 4, 1, 4, 4, 4>;    //  32 x 512, likewise
-using S64 = Cfg<2, 2, 1, 1, 4, 2>;     //  64 x 64   short sequences: many small, deep-chunk tiles
-using S64G = Cfg<1, 4, 2, 1, 4, 2>;    //  64 x 128  short sequences, gated rows (needs TM even)
-using S32 = Cfg<1, 4, 1, 1, 4, 2>;     //  32 x 128
-
 int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
-#ifdef HSP_ONLY_CFG
-  return launch<HSP_ONLY_CFG>(a, s, plan_out);
-#else
   const bool gated = a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU;
+  const bool act = a.prologue == HSP_PRO_ACT1D;
   // "short": even 128 x 128 tiles would leave CUs idle; prefer small tiles with deep chunks so
   // that every CU gets work and each tile sees few global-load round trips
   const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B < 256;
-  if ((short_seq || a.ln_c1 || a.split_row) && !(a.debug & 128)) {
+  if ((short_seq || a.ln_c1 || a.split_row) && !HSP_DBG(a, 128)) {
     // 1x1 GEMMs over a few thousand token columns: the latency-oriented kernel (hsp_tokgemm.hip)
     const int e = hsp_tokgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
   if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused input LayerNorm / second output: token-GEMM path only
+  int epi = select_epilogue(a);
+  if (act && epi != HSP_EPI_INIT) epi = HSP_EPI_GEN;  // the activation shapes carry INIT and GEN only
   if (short_seq) {
-    if (gated) return launch<S64G>(a, s, plan_out);
-    if (a.M > 32) return launch<S64>(a, s, plan_out);
-    return launch<S32>(a, s, plan_out);
+    if (gated) return hsp_conv_tile_S64G(a, epi, act, s, plan_out);
+    if (a.M > 32) return hsp_conv_tile_S64(a, epi, act, s, plan_out);
+    return hsp_conv_tile_S32(a, epi, act, s, plan_out);
   }
-  if (a.debug & 256) return launch<M128>(a, s, plan_out);   // tuning: force a tile shape (results stay right)
-  if (a.debug & 1024) return launch<M64>(a, s, plan_out);
-  if (a.debug & 4096) return launch<S64>(a, s, plan_out);
-  if (a.debug & 8192) return launch<M64P>(a, s, plan_out);
-  if (a.debug & 16384) return launch<M256>(a, s, plan_out);
-  if (a.M > 128) {
-    // 256 x 128 tiles run one per CU, 128 x 128 tiles two per CU at half the work each: in units of
-    // one 128 x 128 tile's MFMA time a CU spends 2 ceil(n256 / 256) against ceil(n128 / 256).
-    // The small tile wins whenever the large one leaves CUs idle (SourceNetwork, L = 400), and on
-    // ties too (a second resident workgroup hides the other's epilogue: 97.7 -> 96.4 ms per step).
-    const int64_t nt = (a.ncols + 127) / 128;
-    const int64_t n256 = (int64_t)((a.M + 255) / 256) * nt * a.B, n128 = (int64_t)((a.M + 127) / 128) * nt * a.B;
-    if ((n128 + 255) / 256 <= 2 * ((n256 + 255) / 256) && !(a.debug & 32768)) return launch<M128>(a, s, plan_out);
-    return launch<M256>(a, s, plan_out);
-  }
-  if (a.M > 64) return launch<M128>(a, s, plan_out);
-  const bool plain_in = a.prologue != HSP_PRO_ACT1D && !(a.debug & 2048);
-  if (a.M > 32) return plain_in ? launch<M64P>(a, s, plan_out) : launch<M64>(a, s, plan_out);
-  return plain_in ? launch<M32P>(a, s, plan_out) : launch<M32>(a, s, plan_out);
+  if (gated) return hsp_conv_tile_M128(a, epi, act, s, plan_out);
+#ifdef HSP_TUNING
+  // force a tile shape (results stay right)
+  if (a.debug & 256) return hsp_conv_tile_M128(a, epi, act, s, plan_out);
+  if (a.debug & 1024) return hsp_conv_tile_M64(a, epi, act, s, plan_out);
+  if (a.debug & 4096) return hsp_conv_tile_S64(a, epi, act, s, plan_out);
+  if (a.debug & 8192) return hsp_conv_tile_M64P(a, epi, act, s, plan_out);
 #endif
+  // M > 128: 128 x 128 tiles at two workgroups per CU.  (A 256 x 128 one-per-CU shape existed in round 1; in
+  // units of one 128 x 128 tile's MFMA time a CU spends 2 ceil(n256 / 256) against ceil(n128 / 256) <= that, and
+  // it lost or tied on every layer of the path, so it is gone.)
+  if (a.M > 64) return hsp_conv_tile_M128(a, epi, act, s, plan_out);
+  if (a.M > 32) return act ? hsp_conv_tile_M64(a, epi, act, s, plan_out) : hsp_conv_tile_M64P(a, epi, act, s, plan_out);
+  return act ? hsp_conv_tile_M32(a, epi, act, s, plan_out) : hsp_conv_tile_M32P(a, epi, act, s, plan_out);
 }
 
 }  // namespace

@@ -6,6 +6,23 @@
 
 #define HSP_WAVE 64
 
+// Raise a kernel's dynamic-LDS limit to `bytes` once per device.  hipFuncSetAttribute applies to the current
+// device only, so the "already raised" flag is kept per device (`flags`: one zero-initialised static array per
+// kernel instantiation).  Idempotent and safe from several host threads; kept out of the launch path afterwards
+// so that launches stay legal inside a hipGraph stream capture.  Returns 0 or the hipError_t / HSP_EINVAL.
+#include <atomic>
+constexpr int HSP_MAX_DEVICES = 32;
+struct hsp_lds_flags { std::atomic<int> raised[HSP_MAX_DEVICES]; };
+inline int hsp_raise_lds_limit(const void* kernel, int bytes, hsp_lds_flags& flags) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HSP_MAX_DEVICES) return HSP_EINVAL;
+  if (flags.raised[dev].load(std::memory_order_acquire)) return 0;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  flags.raised[dev].store(1, std::memory_order_release);
+  return 0;
+}
+
 __device__ __forceinline__ float hsp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 (v_exp_f32) and a true division: ~12 instructions

@@ -16,6 +16,13 @@
 // stride and 16-B addressable rows; every out-of-range 16-B lane group reads the zero buffer.
 #include "hsp_device.h"
 
+// tuning switches exist only in the -DHSP_TUNING build (libhsp_tune.so)
+#ifdef HSP_TUNING
+#define TG_DBG(a, bit) (((a).debug & (bit)) != 0)
+#else
+#define TG_DBG(a, bit) false
+#endif
+
 namespace {
 
 // tile 64 x 64.  A consumer group eats 48 input channels per stage.
@@ -114,7 +121,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     };
     const int npre = nstage < TG_ST ? nstage : TG_ST;
     for (int s = 0; s < npre; ++s) issue(s);
-    float s1 = 0.0f, s2 = 0.0f;                         // fused LayerNorm: column sums of x and x^2
+    // fused LayerNorm: column sums of (x - pivot) and (x - pivot)^2, pivot = the column's first channel.  Shifting
+    // by a sample of the column keeps var = E[d^2] - E[d]^2 free of the cancellation that the raw moments suffer
+    // when |mean| >> std (the residual stream of a real checkpoint), at one subtraction per element.
+    float s1 = 0.0f, s2 = 0.0f, pivot = 0.0f;
     for (int s = 0; s < nstage; ++s) {
       const int issued = (s + TG_ST < nstage ? s + TG_ST : nstage) - (s + 1);  // stages in flight behind s
       if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
@@ -125,21 +135,23 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
         // this wave's share of the stage's rows (pw, pw+4, ...), lane = column; padded rows are zero
         const float* Xs = lds + (s % TG_ST) * STAGE + KS * TG_BM + lane;
         const int rows = K - s * KS < KS ? K - s * KS : KS;
+        if (s == 0) pivot = Xs[0];                      // row 0 of stage 0: the same value in all four waves
         for (int r = pw; r < rows; r += 4) {
-          const float v = Xs[r * TG_BN];
+          const float v = Xs[r * TG_BN] - pivot;
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
       }
       if (s + TG_ST < nstage) {
         tg_barrier();                                   // B_s: consumers are done with this slot
-        if (!(a.debug & 1)) issue(s + TG_ST);
+        if (!TG_DBG(a, 1)) issue(s + TG_ST);
       }
     }
     if (a.ln_c1) {
-      float* st = lds + TG_ST * STAGE;                  // [4 producer waves][2][64]
+      float* st = lds + TG_ST * STAGE;                  // [4 producer waves][2][64] + pivot[64]
       st[(pw * 2 + 0) * 64 + lane] = s1;
       st[(pw * 2 + 1) * 64 + lane] = s2;
+      if (pw == 0) st[8 * 64 + lane] = pivot;
       tg_barrier();                                     // C: statistics are in LDS
     }
     return;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     const float* Xs = lds + (s % TG_ST) * STAGE + KS * TG_BM + (grp * TG_KH + half) * TG_BN + wn * 32 + l32;
     int rows = K - s * KS - grp * TG_KH;
     rows = rows < 0 ? 0 : (rows > TG_KH ? TG_KH : rows);
-    if (a.debug & 2) rows = 0;
+    if (TG_DBG(a, 2)) rows = 0;
     if (rows == TG_KH) {
       const unsigned wa = tg_lds_addr(Ws), xa = tg_lds_addr(Xs);
       tg_read4<0>(A0, B0, wa, xa);
@@ -206,8 +218,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
     const float* st = lds + TG_ST * STAGE + wn * 32 + l32;
     const float t1 = (st[0 * 64] + st[2 * 64]) + (st[4 * 64] + st[6 * 64]);
     const float t2 = (st[1 * 64] + st[3 * 64]) + (st[5 * 64] + st[7 * 64]);
-    mean = t1 / (float)K;
-    const float var = fmaxf(t2 / (float)K - mean * mean, 0.0f);
+    const float dm = t1 / (float)K;                     // mean of (x - pivot)
+    mean = st[8 * 64] + dm;
+    const float var = fmaxf(t2 / (float)K - dm * dm, 0.0f);
     rstd = 1.0f / sqrtf(var + a.ln_eps);
   }
 
@@ -250,14 +263,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, 1) void tokgemm_kernel(const hsp
 template <bool SPLIT>
 int tg_launch(const hsp_conv1d_args& a, hipStream_t s, int n_mt, int n_nt, int64_t blocks) {
   constexpr int KS = SPLIT ? 2 * TG_KH : TG_KH;
-  const size_t lds_bytes = (size_t)TG_ST * KS * (TG_BM + TG_BN) * sizeof(float) + 2048;  // + LayerNorm partials
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_kernel<SPLIT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const size_t lds_bytes = (size_t)TG_ST * KS * (TG_BM + TG_BN) * sizeof(float) + 2304;  // + LayerNorm partials and pivot
+  static hsp_lds_flags flags;
+  if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(tokgemm_kernel<SPLIT>), (int)lds_bytes, flags)) return e;
   hipLaunchKernelGGL(tokgemm_kernel<SPLIT>, dim3((unsigned)blocks), dim3(SPLIT ? 768 : 512), lds_bytes, s, a, n_mt, n_nt);
   return (int)hipGetLastError();
 }
@@ -281,10 +289,10 @@ int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) 
   const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
   if (blocks <= 0 || blocks > 0x7fffffff) return -1;
   // up to one tile per CU: halve each tile's serial chain; beyond: two resident tiles per CU
-  const bool split = (a.debug & 256) ? true : ((a.debug & 512) ? false : blocks <= 256);
+  const bool split = TG_DBG(a, 256) ? true : (TG_DBG(a, 512) ? false : blocks <= 256);
   if (plan_out) {  // {BM, BN, 0 = "token GEMM" (the conv kernel reports its chunk depth here), LDS bytes}
     plan_out[0] = TG_BM; plan_out[1] = TG_BN; plan_out[2] = 0;
-    plan_out[3] = (int32_t)((size_t)TG_ST * (split ? 2 : 1) * TG_KH * (TG_BM + TG_BN) * sizeof(float) + 2048);
+    plan_out[3] = (int32_t)((size_t)TG_ST * (split ? 2 : 1) * TG_KH * (TG_BM + TG_BN) * sizeof(float) + 2304);
     return 0;
   }
   return split ? tg_launch<true>(a, s, n_mt, n_nt, blocks) : tg_launch<false>(a, s, n_mt, n_nt, blocks);

@@ -27,7 +27,9 @@ from .synth import kaiser_sinc_filter12
 # Optional measurement hook (bench.py): called as hook(kind, flops, bytes, ev_start, ev_end, args)
 # with torch.cuda.Events recorded around the launch on the launch stream.
 LAUNCH_HOOK = None
-DEBUG_FLAGS = int(os.environ.get("HSP_CONV_DEBUG", "0"))  # hsp_conv1d_args.debug for every conv launch (kernel tuning only)
+# hsp_conv1d_args.debug of every conv launch.  Always 0 in the product: the release libhsp.so refuses anything
+# else.  tools/ set it programmatically together with HSP_LIB=.../libhsp_tune.so (kernel decomposition runs).
+DEBUG_FLAGS = 0
 
 
 _ZEROS = {}

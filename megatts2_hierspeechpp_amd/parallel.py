@@ -68,3 +68,13 @@ def barrier_max(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value: float, device) -> list:
+    """every rank's python float, in rank order (per-rank spread of bench.py's step time)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]

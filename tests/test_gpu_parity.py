@@ -489,6 +489,30 @@ def test_fused_layernorm_gemm_vs_torch(device):
         lin(torch.randn(1, 192, 18).to(device))                     # 18 columns: rows are not 16-B addressable
 
 
+def test_fused_layernorm_survives_a_large_common_mean(device):
+    """Residual streams of real checkpoints carry |mean| >> std.  Raw one-pass moments (E[x^2] - mean^2) lose
+    log2(mean^2 / var) bits there; the kernel shifts every column by its first channel before summing.  Columns
+    with mean 50 and std 1 (ratio 2500) against torch's two-pass LayerNorm -> Linear, in float64 for the reference:
+    the bound below is what fp32 W x itself allows (eps * |mean| * sqrt(K) / std), far below what unshifted
+    moments would give (eps * mean^2 / var ~ 1.5e-4 relative on rstd alone, on outputs of magnitude ~ 1)."""
+    from megatts2_hierspeechpp_amd.hip_layers import LinearCT, finalize
+    from megatts2_hierspeechpp_amd.ttv_v1.transformer_mega import LayerNorm
+    g = torch.Generator().manual_seed(33)
+    cin, cout, N = 276, 828, 256
+    norm, lin = LayerNorm(cin), LinearCT(cin, cout)
+    gamma, beta = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+    w, b = torch.randn(cout, cin, generator=g) / cin ** 0.5, 0.1 * torch.randn(cout, generator=g)
+    norm.weight.data, norm.bias.data, lin.weight.data, lin.bias.data = gamma.clone(), beta.clone(), w.clone(), b.clone()
+    lin.fuse_input_layernorm(norm)
+    finalize(torch.nn.ModuleList([norm, lin]), device)
+    x = torch.randn(1, cin, N, generator=g) + 50.0 * torch.sign(torch.randn(1, 1, N, generator=g))
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(
+        x.double().transpose(1, 2), (cin,), gamma.double(), beta.double(), 1e-5), w.double(), b.double())
+    got = lin(x.to(device)).cpu().double().transpose(1, 2)
+    err = float((got - ref).abs().max())
+    assert err < 2e-4, err          # measured ~3e-5; the unshifted form gave ~1e-3 here
+
+
 # ------------------------------------------------------------ prompt mel (SURVEY §8f N1)
 @pytest.fixture(scope="module")
 def mel_fn(device):

@@ -201,3 +201,73 @@ def test_mel_front_end_host_side():
         MelSpectrogramFixed(n_fft=1280, win_length=640)
     with pytest.raises(_lib.HspError):
         MelSpectrogramFixed(n_fft=1280, power=1.0)
+
+
+# ------------------------------------------------------------------ conv dispatch (no GPU: hsp_conv1d_mfma_plan only validates and selects)
+def _plan_args(B, Cin, L, K, cout, *, rows=0, up=0, dil=1, act=0, res=False, accumulate=False, pro=0, mask=False,
+               cscale=False, scale=1.0, unaligned=False):
+    from megatts2_hierspeechpp_amd import _lib as L_
+    a = L_.Conv1dArgs()
+    gated = rows in (L_.ROWS_GATE_WN, L_.ROWS_GATE_GLU)
+    M = cout * up if rows == L_.ROWS_SHUFFLE else (2 * cout if gated else (cout + 3) // 4 * 4)
+    lout = L * up if rows == L_.ROWS_SHUFFLE else L
+    a.x, a.x_bs, a.x_cs, a.x_ts, a.B, a.Cin, a.Lin = 0x10000, Cin * L, L, 1, B, Cin, L
+    a.w, a.K, a.M, a.dil, a.pad, a.stride, a.zeros, a.w_ld = 0x20000, K, M, dil, (K - 1) * dil // 2, 1, 0x30000, M
+    a.y, a.y_bs, a.y_cs, a.Cout, a.Lout = 0x40000 + (4 if unaligned else 0), cout * lout, lout, cout, lout
+    a.ncols = L + 1 if rows == L_.ROWS_SHUFFLE else L
+    a.rows, a.up, a.gate_half, a.scale, a.post_scale, a.act, a.prologue = rows, up, cout if gated else 0, scale, 1.0, act, pro
+    if pro == L_.PRO_ACT1D:
+        a.alpha_exp, a.beta_inv, a.filt = 0x50000, 0x51000, 0x52000
+    if res:
+        a.res, a.res_bs, a.res_cs = 0x60000, cout * lout, lout
+    if mask:
+        a.mask, a.mask_bs, a.mask_mode = 0x70000, lout, L_.MASK_PRE
+    if cscale:
+        a.cscale, a.cscale_bs = 0x80000, cout
+    a.accumulate = int(accumulate)
+    return a
+
+
+def test_conv_dispatch_covers_every_host_side_combination():
+    """Every (tile shape, epilogue kind, activation prologue) the dispatcher can route to must exist in the
+    library: walk short / long sequences x channel widths x row modes x epilogue features through
+    hsp_conv1d_mfma_plan (validation + selection, no launch)."""
+    from megatts2_hierspeechpp_amd import _lib as L_
+    lib = L_.lib()
+    plan = (ctypes.c_int32 * 4)()
+    seen = set()
+    for B, L in ((1, 37), (2, 200), (32, 200), (32, 4000)):
+        for C_ in (32, 48, 64, 128, 192, 256, 512):
+            for K, dil in ((1, 1), (3, 1), (7, 3), (11, 5)):
+                combos = [dict(), dict(res=True), dict(res=True, accumulate=True), dict(act=L_.ACT_TANH),
+                          dict(mask=True, res=True), dict(cscale=True, res=True), dict(scale=0.5),
+                          dict(act=L_.ACT_GELU_TANH, unaligned=True), dict(pro=L_.PRO_LRELU, res=True),
+                          dict(pro=L_.PRO_ACT1D), dict(pro=L_.PRO_ACT1D, res=True, accumulate=True),
+                          dict(pro=L_.PRO_ACT1D, act=L_.ACT_TANH),
+                          dict(rows=L_.ROWS_GATE_WN), dict(rows=L_.ROWS_GATE_GLU, mask=True, res=True),
+                          dict(rows=L_.ROWS_SHUFFLE, up=2), dict(rows=L_.ROWS_SHUFFLE, up=5, res=True)]
+                for kw in combos:
+                    if kw.get("rows") in (L_.ROWS_GATE_WN, L_.ROWS_GATE_GLU) and C_ % 32:
+                        continue
+                    a = _plan_args(B, C_, L, K, C_, dil=dil, **kw)
+                    rc = lib.hsp_conv1d_mfma_plan(ctypes.byref(a), ctypes.byref(plan))
+                    assert rc == 0, (B, L, C_, K, dil, kw)
+                    seen.add((plan[0], plan[1]))
+    # the sweep reaches every tile shape, and the token GEMM (reported as 64 x 64 with KC = 0)
+    assert {(128, 128), (64, 256), (32, 512), (64, 64), (64, 128), (32, 128)} <= seen, seen
+
+
+def test_release_library_refuses_the_tuning_word():
+    """hsp_conv1d_args.debug selects kernel tuning switches that exist only in libhsp_tune.so; the shipped
+    library must reject any non-zero value instead of silently producing wrong audio."""
+    from megatts2_hierspeechpp_amd import _lib as L_
+    if os.environ.get("HSP_LIB"):
+        pytest.skip("HSP_LIB selects a non-default library")
+    lib = L_.lib()
+    plan = (ctypes.c_int32 * 4)()
+    a = _plan_args(32, 128, 4000, 3, 128, res=True)
+    assert lib.hsp_conv1d_mfma_plan(ctypes.byref(a), ctypes.byref(plan)) == 0
+    for bits in (1, 2, 16, 256, 32768):
+        a.debug = bits
+        assert lib.hsp_conv1d_mfma_plan(ctypes.byref(a), ctypes.byref(plan)) == L_.EINVAL
+    assert "HSP_CONV_DEBUG" not in open(os.path.join(os.path.dirname(L_.__file__), "hip_layers.py")).read()

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] (full text -> wav, batch 16) and configs[3] (vocoder + SpeechSR48, batch 32)
+as functions: bench.py prints them as `extra_configs` beside the headline; tools/tts_bench.py and
+tools/sr_bench.py are the stand-alone command lines.
+
+Each function returns a dict {value, unit, ms_per_step, rtf, stage_ms, roofline, config}.  `roofline` is for the
+kernel that takes most of the time among the launches behind the hsp_conv1d entry points (conv1d_mfma_kernel
+or the token GEMM): algorithmic FLOP and bytes of its launches / their summed duration, from one extra eager
+pass with a HIP-event pair per launch on the launch stream."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+VOC_CFG = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,
+               p_dropout=0.1, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+               upsample_rates=[4, 5, 4, 2, 2], upsample_initial_channel=1024, upsample_kernel_sizes=[8, 11, 8, 4, 4],
+               gin_channels=256)
+TTV_CFG = dict(inter_channels=256, hidden_channels=256, filter_channels=1024, n_heads=4, n_layers=6, kernel_size=3,
+               p_dropout=0.1, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+               use_spectral_norm=False)
+
+
+def event_median_ms(fn, steps):
+    """median over `steps` calls of fn(), each bracketed by a HIP-event pair on the current stream"""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    return float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+
+def conv_entry_profile(fn):
+    """Run fn() once eagerly on ONE stream with an event pair around every launch behind the conv entry points;
+    returns {kernel name: (launches, flop, bytes, ms)}."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from megatts2_hierspeechpp_amd import hip_layers
+    rec = []
+
+    def hook(kind, fl, nb, e0, e1, la):
+        if kind == "hsp_conv1d_mfma_f32":
+            plan = (C.c_int32 * 4)()
+            L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
+            kind = "conv1d_mfma_kernel" if plan[2] > 0 else "tokgemm_kernel"
+        rec.append((kind, fl, nb, e0, e1))
+
+    saved = (hss.AMP_STREAMS, hss.FRONT_SPLITS)
+    hss.AMP_STREAMS, hss.FRONT_SPLITS = 0, 1
+    hip_layers.LAUNCH_HOOK = hook
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        hip_layers.LAUNCH_HOOK = None
+        hss.AMP_STREAMS, hss.FRONT_SPLITS = saved
+    agg = {}
+    for kind, fl, nb, e0, e1 in rec:
+        n, f, b, m = agg.get(kind, (0, 0, 0, 0.0))
+        agg[kind] = (n + 1, f + fl, b + nb, m + e0.elapsed_time(e1))
+    return agg
+
+
+def dominant_roofline(agg):
+    if not agg:
+        return None
+    kind, (n, fl, nb, ms) = max(agg.items(), key=lambda kv: kv[1][3])
+    tf = fl / (ms * 1e-3) / 1e12
+    gbs = nb / (ms * 1e-3) / 1e9
+    mfma_frac, hbm_frac = tf / FP32_MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+    bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
+    return {"kernel": kind, "bound": bound,
+            "achieved": tf if bound == "mfma" else gbs, "peak": FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(mfma_frac, hbm_frac),
+            "mfma_frac": mfma_frac, "hbm_frac": hbm_frac, "launches_per_step": n, "kernel_ms_per_step": ms,
+            "algorithmic_gflop_per_step": fl / 1e9, "algorithmic_mb_per_step": nb / 1e6, "traffic": None,
+            "timing": "one extra eager step on one stream, event pair per launch"}
+
+
+# ----------------------------------------------------------------------------- configs[2]
+def tts_b16(dev, steps=3, warmup=1, batch=16, phones=40, use_graph=True, models=None):
+    """16 utterances x 40 phones x 10 frames (durations pinned) -> 200 PLM steps, 4 s each."""
+    from megatts2_hierspeechpp_amd import inference_plm as IP, synth
+    B, N = batch, phones
+    if models is None:
+        models = IP.TtsModels(VOC_CFG, TTV_CFG)
+        models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0))
+                                for k, v in models.state_dict().items()})
+        models.finalize(dev)
+    r = np.random.default_rng(3)
+    ids = torch.from_numpy(r.integers(12, 113, (B, N))).to(dev)
+    tone = torch.from_numpy(r.integers(0, 11, (B, N))).to(dev)
+    lang = torch.where(ids < 74, 1, 2).to(dev)
+    tlen = torch.full((B,), N, dtype=torch.int64, device=dev)
+    mel = torch.from_numpy(synth.synth_inputs(B, 150, seed=5)["mel"]).to(dev)
+    mlen = torch.full((B,), 150, dtype=torch.int64, device=dev)
+    mel2, mlen2 = torch.cat([mel, mel]), torch.cat([mlen, mlen])
+    dur = torch.full((B, N), 10.0, device=dev)
+    T2 = N * 10 // 2
+    noise = torch.from_numpy(r.standard_normal((B, 192, T2)).astype(np.float32)).to(dev)
+    plm_graph = {}
+
+    def plm_infer(x_frame, eager=False):
+        if eager or not use_graph:
+            return models.plm.infer(x_frame)
+        if "g" not in plm_graph:
+            plm_graph["x"] = x_frame.clone()
+            models.plm.infer(plm_graph["x"])
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                plm_graph["codes"] = models.plm.infer(plm_graph["x"])
+            plm_graph["g"] = g
+        plm_graph["x"].copy_(x_frame)
+        plm_graph["g"].replay()
+        return plm_graph["codes"]
+
+    def step(ev=None, eager=False):
+        mark = (lambda: ev.append(torch.cuda.Event(enable_timing=True)) or ev[-1].record()) if ev is not None \
+            else (lambda: None)
+        mark()
+        x_frame, g, x_lengths, x_mask = models.ttv.inf_extract_tc_latent(ids, tlen, mel, mlen, tone, lang, dur=dur)
+        mark()
+        codes = plm_infer(x_frame, eager)
+        mark()
+        w2v, pitch = models.ttv.inf_plm_gen(x_frame, g, codes, x_lengths, x_mask)
+        pitch = IP.zero_below(pitch, float(np.log(55.0)))
+        mark()
+        frames = torch.ceil(x_lengths).to(torch.int64)
+        audio = models.voc.voice_conversion_noise_control(w2v, frames, mel2, mlen2, pitch.unsqueeze(1),
+                                                          noise_scale=0.333, denoise_ratio=0.0, noise=noise)
+        mark()
+        wav = IP.peak_int16(audio, frames * 320)
+        mark()
+        return wav
+
+    for _ in range(max(warmup, 1)):
+        wav = step()
+    torch.cuda.synchronize()
+    assert wav.shape == (B, 320 * T2), wav.shape
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wav = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    ev = []
+    step(ev)
+    torch.cuda.synchronize()
+    names = ["front_end(A16-A17)", "plm_loop(A18)", "w2v+pitch(A17)", "vocoder(A1-A14)", "int16_post(A19)"]
+    stages = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
+    roof = dominant_roofline(conv_entry_profile(lambda: step(None, eager=True)))
+    return {"metric": "16kHz audio samples/sec, full inference_plm.py text->wav, batch=16 (BASELINE.json configs[2])",
+            "value": B * 320 * T2 / el, "unit": "samples/s", "ms_per_step": el * 1e3,
+            "rtf": el / (B * 320 * T2 / 16000.0), "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
+            "config": {"workload": f"tts: {B} utterances x {N} phones x 10 frames -> {320 * T2 / 16000:g} s each, "
+                                   "prompt mel 150 frames", "plm_steps": T2,
+                       "plm_launch_mode": "hipGraph" if use_graph else "eager"},
+            "stage_ms": stages, "roofline": roof}
+
+
+# ----------------------------------------------------------------------------- configs[3]
+def sr48_b32(dev, steps=5, batch=32, net=None):
+    """vocoder (32 x 4 s) -> SpeechSR48: 48 kHz output samples / s of the two-stage pipeline, hipGraph replay."""
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SpeechSR
+    sr = SpeechSR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [3], 32, [3])
+    if net is None:
+        net = SynthesizerTrn(641, 192, **VOC_CFG)
+        net.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0))
+                             for k, v in net.state_dict().items()})
+        net.finalize(dev)
+    sr.load_state_dict({k: torch.from_numpy(synth.synth_tensor("sr." + k, tuple(v.shape), 0))
+                        for k, v in sr.state_dict().items()})
+    finalize(sr, dev)
+    B, T = batch, 200
+    inp = synth.synth_inputs(B, T, seed=1)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+
+    def step():
+        o, _ = net.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+        return o, sr(o)
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o16, o48 = step()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    o, _ = net.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+    e[1].record()
+    sr(o)
+    e[2].record()
+    torch.cuda.synchronize()
+    assert o48.shape == (B, 1, 3 * 320 * T) and bool(torch.isfinite(o48).all())
+    roof = dominant_roofline(conv_entry_profile(lambda: sr(o)))
+    if roof:
+        roof["scope"] = "SpeechSR48 stage only (the vocoder stage is the headline's roofline)"
+    return {"metric": "48 kHz samples/s, vocoder + SpeechSR48, batch=32 (BASELINE.json configs[3])",
+            "value": B * 3 * 320 * T / el, "unit": "samples/s", "ms_per_step": el * 1e3,
+            "rtf": el / (B * 320 * T / 16000.0), "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
+            "config": {"workload": f"vocoder infer() {B} x 4 s -> SpeechSR48 (x3 linear interp + AMP block, C=32)",
+                       "launch_mode": "hipGraph replay of both stages"},
+            "stage_ms": {"vocoder_eager": e[0].elapsed_time(e[1]), "speechsr48_eager": e[1].elapsed_time(e[2])},
+            "roofline": roof}
