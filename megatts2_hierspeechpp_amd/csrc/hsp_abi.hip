@@ -3,6 +3,9 @@
 // hsp_layernorm_mod_f32) with the selection rule the Python mirror (hip_layers.Conv1d.forward) applies.
 #include "hsp_device.h"
 
+int hsp_gemm2_try(const hsp_conv1d_args& in, const hsp_conv1d_args& o1, const hsp_conv1d_args* o2, hipStream_t s,
+                  bool dry_run);  // hsp_gemm2.hip
+
 namespace {
 // shapes the MFMA kernels do not take (stride, degenerate channel / length counts, SiLU prologue) go to the VALU kernel
 bool wants_direct(const hsp_conv1d_args& a) {
@@ -26,10 +29,31 @@ extern "C" int hsp_wn_layer_f32(const hsp_conv1d_args* in_layer, const hsp_conv1
                                 void* stream) {
   if (!in_layer || in_layer->rows != HSP_ROWS_GATE_WN || (!res && !skip)) return HSP_EINVAL;
   if ((res && res->rows != HSP_ROWS_PLAIN) || (skip && skip->rows != HSP_ROWS_PLAIN)) return HSP_EINVAL;
+  // one launch: gated in-conv -> activations in LDS -> res / skip GEMM -> residual + skip epilogue (hsp_gemm2.hip)
+  {
+    const int e = res ? hsp_gemm2_try(*in_layer, *res, skip, static_cast<hipStream_t>(stream), false)
+                      : hsp_gemm2_try(*in_layer, *skip, nullptr, static_cast<hipStream_t>(stream), false);
+    if (e >= 0) return e;
+  }
+  // shapes the fused kernel does not take (H not a multiple of 192, unaligned tensors, ...): layer by layer
   if (int e = hsp_conv1d_mfma_f32(in_layer, stream)) return e;
   if (res)
     if (int e = hsp_conv1d_f32(res, stream)) return e;
   return skip ? hsp_conv1d_f32(skip, stream) : 0;
+}
+
+extern "C" int hsp_fused_pair_supported(const hsp_conv1d_args* first, const hsp_conv1d_args* second,
+                                       const hsp_conv1d_args* third) {
+  if (!first || !second) return 0;
+  return hsp_gemm2_try(*first, *second, third, nullptr, true) == 0 ? 1 : 0;
+}
+
+extern "C" int hsp_ffn_conv_f32(const hsp_conv1d_args* fc1, const hsp_conv1d_args* fc2, void* stream) {
+  if (!fc1 || !fc2 || fc1->rows != HSP_ROWS_PLAIN || fc2->rows != HSP_ROWS_PLAIN) return HSP_EINVAL;
+  const int e = hsp_gemm2_try(*fc1, *fc2, nullptr, static_cast<hipStream_t>(stream), false);
+  if (e >= 0) return e;
+  if (int e1 = hsp_conv1d_f32(fc1, stream)) return e1;
+  return hsp_conv1d_f32(fc2, stream);
 }
 
 extern "C" int hsp_layernorm_modulate_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, float eps,

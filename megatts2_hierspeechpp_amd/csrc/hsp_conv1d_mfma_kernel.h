@@ -218,6 +218,46 @@ struct Prod {
       }
     }
   }
+  // ---- fast staging: no per-instruction vector arithmetic.  The fp32 MFMAs of the consumer wave on the same
+  // SIMD run on the VALU's own FMA lanes, so every address computation above (a 32-bit multiply, 64-bit adds,
+  // selects: ~10 VALU instructions per DMA) is paid in matrix time (measured: 12 % of a k = 3 launch).  Here a
+  // lane's byte offset is computed ONCE per tile and each instruction adds it to a wave-uniform base that the
+  // scalar unit walks.  Preconditions (wave-uniform, checked by the kernel): the row tile lies inside [0, M),
+  // Cin % KC == 0 (no channel tail), 16-B addressable window.
+  static __device__ __forceinline__ void dma_w_fast(const float* wtile, int w_ld, int Cin, int K, const LdsPlan& P,
+                                                    float* Ws, int c0, int pw, unsigned wofs) {
+    const int lipj = P.lkc - __builtin_ctz(RPI);
+    const int ninstr = K << lipj;
+    for (int q = pw; q < ninstr; q += C::NPW) {
+      const int j = q >> lipj, g = q & ((1 << lipj) - 1);
+      const char* base = reinterpret_cast<const char*>(wtile + (size_t)(j * Cin + c0 + g * RPI) * (size_t)w_ld);  // uniform
+      dma16(reinterpret_cast<const float*>(base + wofs), Ws + ((j << P.lkc) + g * RPI) * C::BM);
+    }
+  }
+  // window rows: `xtile` = row 0 of the utterance + p0a (may point before the row: such lanes are masked).
+  // Lanes whose 4-group lies outside [0, Lin) take no part (EXEC-masked DMA lanes write nothing); the kernel
+  // zero-fills those LDS positions once per tile (zero_x_rows).
+  static __device__ __forceinline__ void dma_x16_fast(const float* xtile, int x_cs, int Lin, const LdsPlan& P, float* Xa,
+                                                      int c0, int p0a, int pw, int lane) {
+    const int ngrp = (P.xw + 3 + 3) >> 2;
+    for (int g0 = 0; g0 < ngrp; g0 += 64) {
+      const int g = g0 + lane, p = p0a + 4 * g;
+      if (g < ngrp && p >= 0 && p < Lin) {
+        const unsigned xofs = 16u * (unsigned)lane;
+        for (int kc = pw; kc < P.kc; kc += C::NPW) {
+          const char* base = reinterpret_cast<const char*>(xtile + (size_t)(c0 + kc) * (size_t)x_cs + 4 * g0);  // uniform
+          dma16(reinterpret_cast<const float*>(base + xofs), Xa + kc * P.xwp + 4 * g0);
+        }
+      }
+    }
+  }
+  // rows this wave stages (kc = pw, pw + NPW, ...) of BOTH window buffers <- 0 (edge tiles only)
+  static __device__ __forceinline__ void zero_x_rows(const LdsPlan& P, float* Xa0, int pw, int lane) {
+    for (int bsel = 0; bsel < 2; ++bsel)
+      for (int kc = pw; kc < P.kc; kc += C::NPW)
+        for (int s = lane; s < P.xwp; s += 64) Xa0[bsel * P.xa_sz + kc * P.xwp + s] = 0.0f;
+    wave_lds_fence();  // the zeros have landed before this wave's DMA may write the same rows
+  }
   static __device__ __forceinline__ void lrelu_x(const ProdArgs& a, const LdsPlan& P, float* Xa, int pw, int lane) {
     for (int kc = pw; kc < P.kc; kc += C::NPW)
       for (int s = lane; s < P.xwp; s += 64) {
@@ -357,6 +397,30 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
     float* const Xa0 = lds + P.xa_off;
     if constexpr (!ACT) {
       const int p0a = p0 & ~3;
+      const bool fast = xvec && m0 + BM <= a.M && (a.Cin & (KC - 1)) == 0 && !HSP_DBG(a, 512);  // wave-uniform
+      if (fast) {
+        const float* const wtile = a.w + m0;
+        const float* const xtile = xb + p0a;
+        const int xcs = (int)a.x_cs;
+        const unsigned wofs = 4u * (unsigned)((lane / PR::CPR) * a.w_ld + (lane % PR::CPR) * 4);
+        if (p0a < 0 || p0a + 4 * ((P.xw + 3 + 3) >> 2) > a.Lin) PR::zero_x_rows(P, Xa0, pw, lane);
+        PR::dma_w_fast(wtile, a.w_ld, a.Cin, a.K, P, Ws0, 0, pw, wofs);
+        PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0, 0, p0a, pw, lane);
+        wait_vm0();
+        if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
+        lds_barrier();
+        for (int c = 0; c < nchunks; ++c) {
+          const int nb = (c + 1) & 1;
+          if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
+            PR::dma_w_fast(wtile, a.w_ld, a.Cin, a.K, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, pw, wofs);
+            PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0a, pw, lane);
+            wait_vm0();
+            if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
+          }
+          lds_barrier();
+        }
+        return;
+      }
       PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
       if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
       wait_vm0();

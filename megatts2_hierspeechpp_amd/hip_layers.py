@@ -48,17 +48,51 @@ def _zeros(device) -> torch.Tensor:
 # default; with SURVEY_ABI set (HSP_SURVEY_ABI=1) every launch goes through them instead - same kernels, same
 # results (tests/test_gpu_parity.py::test_survey_abi_names_give_identical_results).
 SURVEY_ABI = os.environ.get("HSP_SURVEY_ABI", "0") == "1"
-_DEFER = None  # a list while modules.WN collects the launches of one layer for hsp_wn_layer_f32
+_DEFER = None  # a list while a caller collects the argument structs of several layers for ONE fused entry point
+# (modules.WN -> hsp_wn_layer_f32, modules.DiTConVBlock -> hsp_ffn_conv_f32): _launch() then records instead of launching
+
+
+class deferred:
+    """``with deferred() as args:`` -- conv layers called inside only build their hsp_conv1d_args (outputs are
+    allocated as usual); the caller passes the collected structs to a fused entry point with launch_group()."""
+
+    def __enter__(self):
+        global _DEFER
+        assert _DEFER is None
+        _DEFER = []
+        return _DEFER
+
+    def __exit__(self, *exc):
+        global _DEFER
+        _DEFER = None
+        return False
+
+
+def launch_group(kind: str, fn, structs, *extra):
+    """One call into a fused entry point taking several hsp_conv1d_args; measurement hook as for _launch().
+    ``structs``: the (args, flops, bytes) entries collected by deferred(); a None entry is passed as NULL."""
+    flops = sum(e[1] for e in structs if e is not None)
+    nbytes = sum(e[2] for e in structs if e is not None)
+    ptrs = [C.byref(e[0]) if e is not None else None for e in structs]
+    hook = LAUNCH_HOOK
+    if hook is None:
+        L.check(fn(*ptrs, *extra, L.stream_ptr()), kind)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(fn(*ptrs, *extra, L.stream_ptr()), kind)
+    e1.record()
+    hook(kind, flops, nbytes, e0, e1, structs[0][0])
 
 
 def _launch(kind: str, fn, a, flops: int, nbytes: int, soft: bool = False):
     """``soft``: return the status instead of raising on HSP_EINVAL (a shape the requested fusion does not
     cover; the caller then issues the un-fused launches)."""
     a.debug = DEBUG_FLAGS
+    if _DEFER is not None:
+        _DEFER.append((a, flops, nbytes))
+        return 0
     if SURVEY_ABI:
-        if _DEFER is not None:
-            _DEFER.append(a)
-            return
         fn = L.lib().hsp_convtr1d_f32 if a.rows == L.ROWS_SHUFFLE else L.lib().hsp_conv1d_f32
     hook = LAUNCH_HOOK
     if hook is None:

@@ -66,36 +66,29 @@ class WN(nn.Module):
             self.res_skip_layers.append(Conv1d(hidden_channels, rs, 1, weight_norm=True))
 
     def forward(self, x, x_mask, g=None, **kwargs):
+        """One hsp_wn_layer_f32 call per layer.  The library runs it as ONE launch where it can (csrc/hsp_gemm2.hip:
+        H = 192, the 50 Hz tensors of the vocoder) and layer by layer otherwise; either way the activations tensor
+        `acts` is only a workspace.  x is never updated in place: the fused kernel's neighbouring column tiles read
+        the old x as their halo."""
         H = self.hidden_channels
         gc = self.cond_layer(g) if g is not None else None  # [B, 2H*n, 1]
         out = None
+        acts = torch.empty(x.shape[0], H, x.shape[2], dtype=torch.float32, device=x.device)
         for i in range(self.n_layers):
             cb = gc[:, 2 * H * i: 2 * H * (i + 1)] if gc is not None else None
-            if hip_layers.SURVEY_ABI:   # the layer's three launches as ONE hsp_wn_layer_f32 call
-                hip_layers._DEFER = []
-            acts = self.in_layers[i](x, cbias=cb)
-            if i < self.n_layers - 1:
-                # both halves of res_skip in one token-GEMM launch where the library has it (T = 200 frames);
-                # two launches otherwise (and under SURVEY_ABI, whose hsp_wn_layer_f32 takes the halves apart)
-                both = None
-                if not hip_layers.SURVEY_ABI and H % 64 == 0:
-                    both = self.res_skip_layers[i](acts, res=x, mask=x_mask, mask_mode=L.MASK_POST,
-                                                   split_out=(H, out, out is not None))
-                if both is not None:
-                    x, out = both
-                    continue
-                x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
-                out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
+            last = i == self.n_layers - 1
+            with hip_layers.deferred() as args:
+                self.in_layers[i](x, cbias=cb, out=acts)
+                if not last:
+                    x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
+                    out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
+                else:
+                    # last layer: output = output + rs (modules.py:175-176); the final * x_mask follows below
+                    out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None)
+            hip_layers.launch_group("hsp_wn_layer_f32", L.lib().hsp_wn_layer_f32,
+                                    [args[0], args[1] if not last else None, args[-1]])
+            if not last:
                 x = x_new
-            else:
-                # last layer: output = (output + rs) * x_mask   (modules.py:175-176)
-                out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None, mask=x_mask,
-                                              mask_mode=L.MASK_NONE)
-            if hip_layers.SURVEY_ABI:
-                args, hip_layers._DEFER = hip_layers._DEFER, None
-                res_a = C.byref(args[1]) if len(args) == 3 else None
-                L.check(L.lib().hsp_wn_layer_f32(C.byref(args[0]), res_a, C.byref(args[-1]), L.stream_ptr()),
-                        "hsp_wn_layer_f32")
         return Fh.mask_mul(out, x_mask)
 
 
@@ -164,9 +157,13 @@ class DiTConVBlock(nn.Module):
         o = Fh.mha(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale)
         x = self.attn.proj(o, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_a, res=x)
         h = Fh.layernorm_mod(x, 1e-6, shift=sh_m, scale=sc_m)
-        y = self.mlp.fc1(h, act=L.ACT_GELU_TANH)
+        # fc1 -> GELU -> fc2 as ONE hsp_ffn_conv_f32 call (one launch where the library has the fused kernel);
         # fc2(y * mask) * mask == (W y + b) * mask for a 1x1 conv and a 0/1 mask
-        return self.mlp.fc2(y, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_m, res=x)
+        with hip_layers.deferred() as args:
+            y = self.mlp.fc1(h, act=L.ACT_GELU_TANH)
+            out = self.mlp.fc2(y, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_m, res=x)
+        hip_layers.launch_group("hsp_ffn_conv_f32", L.lib().hsp_ffn_conv_f32, args)
+        return out
 
 
 class ResidualCouplingLayer_Transformer_simple(nn.Module):

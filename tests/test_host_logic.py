@@ -271,3 +271,51 @@ def test_release_library_refuses_the_tuning_word():
         a.debug = bits
         assert lib.hsp_conv1d_mfma_plan(ctypes.byref(a), ctypes.byref(plan)) == L_.EINVAL
     assert "HSP_CONV_DEBUG" not in open(os.path.join(os.path.dirname(L_.__file__), "hip_layers.py")).read()
+
+
+def test_vocoder_wn_layers_and_dit_ffn_take_the_one_launch_path(monkeypatch):
+    """hsp_wn_layer_f32 / hsp_ffn_conv_f32 run as ONE launch (csrc/hsp_gemm2.hip) for the shapes of the vocoder path:
+    WN H = 192 and the DiT FFN 192 -> 768 -> 192, at 4-s batches, 1-s single utterances and ragged lengths.  Checked
+    through the library's own host-side predicate with the argument structs the host mirror really builds (device
+    pointers replaced by host addresses: nothing is launched)."""
+    from megatts2_hierspeechpp_amd import _lib as L_, hip_layers as HL, modules as M
+    lib = L_.lib()
+    monkeypatch.setattr(L_, "ptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(L_, "fptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(HL, "_zeros", lambda dev: torch.zeros(64))
+    seen = []
+
+    def fake_group(kind, fn, structs, *extra):
+        ptrs = [ctypes.byref(e[0]) if e is not None else None for e in structs]
+        if kind == "hsp_wn_layer_f32":
+            first, second, third = (ptrs[0], ptrs[1], ptrs[2]) if ptrs[1] is not None else (ptrs[0], ptrs[2], None)
+        else:
+            first, second, third = ptrs[0], ptrs[1], None
+        seen.append((kind, lib.hsp_fused_pair_supported(first, second, third)))
+
+    monkeypatch.setattr(HL, "launch_group", fake_group)
+    monkeypatch.setattr(M.Fh, "mask_mul", lambda x, m: x)
+    monkeypatch.setattr(M.Fh, "layernorm_mod", lambda x, *a, **k: torch.empty_like(x))
+    monkeypatch.setattr(M.Fh, "mha", lambda q, k, v, *a, **kw: torch.empty_like(q))
+    monkeypatch.setattr(HL, "_launch", lambda kind, fn, a, fl, nb, soft=False: (HL._DEFER.append((a, fl, nb)) if HL._DEFER is not None else None) or 0)
+    wn = M.WN(192, 5, 1, 3, gin_channels=0)
+    blk = M.DiTConVBlock(192, 2, mlp_ratio=4.0, kernel=5)
+    for m in list(wn.modules()) + list(blk.modules()):
+        if isinstance(m, HL.Conv1d):
+            m._w = torch.zeros(m.k * m.cin * m.M)
+            m._b = torch.zeros(m.cout)
+    for B, T in ((32, 200), (1, 50), (3, 333), (2, 36)):
+        seen.clear()
+        x, mask = torch.zeros(B, 192, T), torch.ones(B, 1, T)
+        wn(x, mask)
+        blk(x, None, mask, mod=torch.zeros(B, 6 * 192, 1), premasked=True)
+        assert [k for k, _ in seen] == ["hsp_wn_layer_f32"] * 3 + ["hsp_ffn_conv_f32"], seen
+        assert all(ok == 1 for _, ok in seen), (B, T, seen)
+    # a WN whose width the fused kernel does not cover runs layer by layer (W2VDecoder: H = 512)
+    seen.clear()
+    wn512 = M.WN(512, 5, 1, 2, gin_channels=0)
+    for m in wn512.modules():
+        if isinstance(m, HL.Conv1d):
+            m._w, m._b = torch.zeros(m.k * m.cin * m.M), torch.zeros(m.cout)
+    wn512(torch.zeros(2, 512, 200), torch.ones(2, 1, 200))
+    assert [ok for _, ok in seen] == [0, 0]
