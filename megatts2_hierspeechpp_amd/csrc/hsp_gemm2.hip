@@ -31,6 +31,20 @@
 #define G2_DBG(a, bit) false
 #endif
 
+// In-kernel stamps (tuning build, debug bit 256): wave 0 (consumer) and wave 8 (producer) of every workgroup write
+// s_memtime at the phase boundaries to the buffer in.filt points to (unused by this kernel otherwise):
+// [block][role 0/1][8] 64-bit ticks.  Diagnostic only; nothing reads the buffer on the device.
+#ifdef HSP_TUNING
+#define G2_STAMP(k)                                                                                         \
+  do {                                                                                                      \
+    if ((in.debug & 256) && lane == 0 && (wave == 0 || wave == G2_NCW))                                     \
+      reinterpret_cast<unsigned long long*>(const_cast<float*>(in.filt))[(blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + (k)] = \
+          __builtin_amdgcn_s_memtime();                                                                     \
+  } while (0)
+#else
+#define G2_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 typedef float g2_f32x16 __attribute__((ext_vector_type(16)));
@@ -72,6 +86,7 @@ template <int N>
 __device__ __forceinline__ void g2_wait4(float& b, float& a0, float& a1, float& a2) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b), "+v"(a0), "+v"(a1), "+v"(a2) : "n"(N));
 }
+__device__ __forceinline__ void g2_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void g2_wait3(float& b, float& a0, float& a1) {
   asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(b), "+v"(a0), "+v"(a1) : "n"(N));
@@ -121,6 +136,11 @@ __device__ __forceinline__ G2Out g2_pick(const hsp_conv1d_args& o1, const hsp_co
 // part yields 384 channels through the pointwise function in.act.
 // MULTI: more than one part (the second GEMM's accumulators then live through phase 1 of the later parts; with a
 // single part they are born after the gate, which keeps the register allocation of phase 1 small).
+//
+// Control flow: producers and consumers run SEPARATE loops with the same barrier sequence
+//   per part: NP1 x [chunk barrier]   3 x [combine / gate barrier]   NP2 x [chunk barrier]      then 2 at the end.
+// (A shared loop with `if (producer) ... else ...` inside makes the accumulators live across the join: the compiler
+// then copies all 48 of them once per chunk -- VALU work, i.e. fp32 MFMA time.)
 template <int NB2PW, bool GATE, bool MULTI>
 __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_args in, const hsp_conv1d_args o1,
                                                               const hsp_conv1d_args o2, const int split,
@@ -131,6 +151,7 @@ __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_a
                                                  // 32 over four waves -> NB2PW = 3 or 2 (the fourth wave idles at 192)
   static_assert(NB2PW == 2 || NB2PW == 3, "M2 is 192 or 384");
   constexpr int KC2 = G2_SLOT / M2;              // channels per phase-2 chunk (16 for M2 = 384, 32 for 192)
+  constexpr int NP2 = CP / KC2;
   const G2Plan P = g2_plan(in.Cin, in.pad);
   float* const xwin = lds;
   float* const U = lds + P.u_off;
@@ -143,79 +164,21 @@ __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_a
   const int t0 = nt * G2_BN;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const bool producer = wave >= G2_NCW;
 
   const int C1 = in.Cin, K1 = in.K;
-  const int nstep1 = (C1 >> 1) * K1;             // MFMA k-steps of phase 1 (channel pair outer, tap inner)
-  const int NP1 = (nstep1 + 7) >> 3;             // chunks of 8 steps
-  const int NP2 = CP / KC2;
+  const int NP1 = ((C1 >> 1) * K1) >> 3;         // phase-1 chunks of 8 k-steps (the host requires a whole number)
   const int NCH = nparts * (NP1 + NP2);          // chunks of the whole schedule
 
-  // ------------------------------------------------------------------ producer state
-  // chunk n -> ring slot n % 3.  A producer wave owns instruction `pw` of every 3-instruction row pair.
-  const int pw = wave - G2_NCW;
-  unsigned off1 = 0, off2 = 0;                   // this lane's byte offset inside a row pair (phase 1 / phase 2)
-  if (producer) {
-    const int f16 = 64 * pw + lane;              // 16-B lane index inside the 192 lanes of a k-step (2 x 384 floats)
-    off1 = 4u * (unsigned)((f16 / 96) * in.w_ld + (f16 % 96) * 4);
-    // phase 2: a chunk is KC2 rows of M2 floats = 24 instructions; instruction q covers 16-B lanes 64 q ..; the lane
-    // pattern repeats every 3 instructions (192 lanes = 768 floats = 2 rows of 384 or 4 rows of 192)
-    const int l4 = M2 >> 2;                      // 16-B lanes per row
-    off2 = 4u * (unsigned)((f16 / l4) * o1.w_ld + (f16 % l4) * 4);
-  }
-  auto issue = [&](int n) __attribute__((always_inline)) {
-    const int part = n / (NP1 + NP2), r = n % (NP1 + NP2);
-    float* const slot = ring + (n % G2_NSLOT) * G2_SLOT;
-    if (r < NP1) {
-      // steps 8 r .. 8 r + 7 of phase 1: step -> (channel pair cp, tap j); its two k-rows are w1[(j C1 + 2 cp)(+1)][part rows]
-      int st = 8 * r;
-      int cp = st / K1, j = st - cp * K1;
-#pragma unroll
-      for (int i = 0; i < G2_IPC; ++i) {
-        const float* src = in.zeros;
-        if (st + i < nstep1) {
-          const char* base = reinterpret_cast<const char*>(in.w + (size_t)(j * C1 + 2 * cp) * in.w_ld + part * G2_R1);
-          src = reinterpret_cast<const float*>(base + off1);
-        }
-        __builtin_amdgcn_global_load_lds(G2_GPTR(src), G2_LPTR(slot + i * 768 + pw * 256), 16, 0, 0);
-        if (++j == K1) { j = 0; ++cp; }
-      }
-    } else {
-      const int k0 = part * CP + (r - NP1) * KC2;   // first W2 row of the chunk
-      const int rows_per3 = 768 / M2;               // 2 or 4 rows per 3 instructions
-#pragma unroll
-      for (int i = 0; i < G2_IPC; ++i) {
-        const char* base = reinterpret_cast<const char*>(o1.w + (size_t)(k0 + i * rows_per3) * o1.w_ld);
-        __builtin_amdgcn_global_load_lds(G2_GPTR(base + off2), G2_LPTR(slot + i * 768 + pw * 256), 16, 0, 0);
-      }
-    }
-  };
-
-  // ------------------------------------------------------------------ consumer state
-  const int grp = wave >> 2, w4 = wave & 3;      // (producers: unused)
-  const int l32 = lane & 31, half = lane >> 5;
-  g2_f32x16 acc1[3], acc2[NB2PW];
-  // epilogue operands, filled before the last phase 2 (when acc1's registers are free): the residual OR the running
-  // sum of an output element (the host refuses to fuse a layer that has both on the same rows), this lane's mask
-  float eop[NB2PW][8], emk[NB2PW];
-  auto zero_acc2 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NB2PW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
-  };
-  if constexpr (MULTI) zero_acc2();
-
+  G2_STAMP(0);
   // ------------------------------------------------------------------ per-row constants -> LDS (everyone; they are
   // read after the first workgroup barrier at the earliest).  Loads issue back to back: one round trip, instead of
   // one per accumulator element in the combine step and the epilogue.
   {
-    constexpr int CPt = GATE ? G2_R1 / 2 : G2_R1;
     for (int idx = threadIdx.x; idx < nparts * G2_R1; idx += G2_THREADS) {
       const int part = idx / G2_R1, m = idx - part * G2_R1;
       int ch;
-      if (GATE) ch = ((m >> 5) & 1) * (CPt * nparts) + part * CPt + (m >> 6) * 32 + (m & 31);
-      else ch = part * CPt + m;
+      if (GATE) ch = ((m >> 5) & 1) * (CP * nparts) + part * CP + (m >> 6) * 32 + (m & 31);
+      else ch = part * CP + m;
       float v = in.bias ? in.bias[ch] : 0.0f;
       if (in.cbias) v += in.cbias[(int64_t)b * in.cbias_bs + ch];
       tab1[idx] = v;
@@ -230,9 +193,44 @@ __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_a
       tab2s[m] = (o.cscale ? o.cscale[(int64_t)b * o.cscale_bs + co] : 1.0f) * o.scale;
     }
   }
+  G2_STAMP(1);
 
-  // ------------------------------------------------------------------ prologue: window + first two chunks
-  if (producer) {
+  if (wave >= G2_NCW) {
+    // ================================================================================================ producers
+    // chunk n -> ring slot n % 3; a producer wave owns instruction `pw` of every 3-instruction row pair / row group
+    const int pw = wave - G2_NCW;
+    const int f16 = 64 * pw + lane;              // 16-B lane index inside the 192 lanes of a k-step (2 x 384 floats)
+    const unsigned off1 = 4u * (unsigned)((f16 / 96) * in.w_ld + (f16 % 96) * 4);
+    // phase 2: a chunk is KC2 rows of M2 floats = 24 instructions; the lane pattern repeats every 3 instructions
+    // (192 lanes = 768 floats = 2 rows of 384 or 4 rows of 192)
+    const unsigned off2 = 4u * (unsigned)((f16 / (M2 >> 2)) * o1.w_ld + (f16 % (M2 >> 2)) * 4);
+    // running schedule position of the NEXT chunk to issue (no division by run-time values inside the loop)
+    int is_part = 0, is_r = 0, is_cp = 0, is_j = 0;
+    auto issue = [&](int n) __attribute__((always_inline)) {
+      float* const slot = ring + (n % G2_NSLOT) * G2_SLOT;
+      if (is_r < NP1) {
+        // 8 k-steps of phase 1: step -> (channel pair cp, tap j); its two k-rows are w1[(j C1 + 2 cp)(+1)][part rows]
+        int cp = is_cp, j = is_j;
+#pragma unroll
+        for (int i = 0; i < G2_IPC; ++i) {
+          const char* base = reinterpret_cast<const char*>(in.w + (size_t)(j * C1 + 2 * cp) * in.w_ld + is_part * G2_R1);
+          __builtin_amdgcn_global_load_lds(G2_GPTR(base + off1), G2_LPTR(slot + i * 768 + pw * 256), 16, 0, 0);
+          if (++j == K1) { j = 0; ++cp; }
+        }
+        is_cp = cp;
+        is_j = j;
+      } else {
+        const int k0 = is_part * CP + (is_r - NP1) * KC2;   // first W2 row of the chunk
+        constexpr int rows_per3 = 768 / M2;                 // 2 or 4 rows per 3 instructions
+#pragma unroll
+        for (int i = 0; i < G2_IPC; ++i) {
+          const char* base = reinterpret_cast<const char*>(o1.w + (size_t)(k0 + i * rows_per3) * o1.w_ld);
+          __builtin_amdgcn_global_load_lds(G2_GPTR(base + off2), G2_LPTR(slot + i * 768 + pw * 256), 16, 0, 0);
+        }
+      }
+      if (++is_r == NP1 + NP2) { is_r = 0; ++is_part; is_cp = 0; is_j = 0; }
+    };
+    // input window of all channels
     const float* xb = in.x + (int64_t)b * in.x_bs;
     if (xvec) {
       const int l4 = P.xp >> 2;                    // 16-B lanes per window row
@@ -259,170 +257,237 @@ __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_a
     }
     issue(0);
     if (NCH > 1) issue(1);
+    G2_STAMP(2);
+    int n = 0;
+    auto chunk_rounds = [&](int count) __attribute__((always_inline)) {
+      for (int c = 0; c < count; ++c, ++n) {
+        if (n + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G2_IPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g2_barrier();                             // chunk n is in LDS; every consumer is done with chunk n - 1
+        if (n + 2 < NCH && !G2_DBG(in, 1)) issue(n + 2);
+      }
+    };
+    for (int part = 0; part < nparts; ++part) {
+      chunk_rounds(NP1);
+      G2_STAMP(3);
+      g2_barrier();
+      g2_barrier();
+      g2_barrier();
+      G2_STAMP(4);
+      chunk_rounds(NP2);
+    }
+    G2_STAMP(6);
+    g2_barrier();
+    g2_barrier();
+    return;
   }
 
-  int n = 0;   // chunk sequence number (uniform across the workgroup)
-  // phase 2 of one part: acc2 += W2[rows of the part] x activations (U)
-  auto phase2 = [&](const int part) __attribute__((always_inline)) {
-    for (int c = 0; c < NP2; ++c, ++n) {
-    if (producer) {
-      if (n + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G2_IPC) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    g2_barrier();                               // (c = 0: the activations are complete in U as well)
-    if (producer) {
-      if (n + 2 < NCH && !G2_DBG(in, 1)) issue(n + 2);
-    } else if (!G2_DBG(in, 2)) {
-      const float* const slot = ring + (n % G2_NSLOT) * G2_SLOT;
-      const int nst = KC2 >> 2;                 // steps per group and chunk: KC2 / 2 steps split in two (4 or 8)
-      const int nblk = (M2 >> 5) - w4 * NB2PW;     // blocks of this wave that exist (wave-uniform; may be <= 0)
-      for (int s0 = 0; s0 < nst; s0 += 4) {
-        float A[4][NB2PW], B[4];
-        // steps ls0 .. ls0 + 3 (ls0 a multiple of 4): activation channels ka0 + 2 s + half with ka0 a multiple of 8,
-        // so the four steps share the 32-channel block of the gated row map and differ by constant offsets
-        const int ls0 = grp * nst + s0;
-        const int ka0 = c * KC2 + 2 * ls0 + half;
-        const int urow0 = GATE ? ka0 + ((ka0 >> 5) << 5) : ka0;
-        const unsigned ua = g2_lds_addr(U + urow0 * G2_BN + l32);
-        // a wave whose blocks lie past M2 (the last wave when M2 / 32 is not a multiple of 4) reads the last NB2PW
-        // blocks instead -- in range, unused: its MFMAs are skipped below -- so every wave issues the same reads
-        const int blk0 = nblk > 0 ? w4 * NB2PW : (M2 >> 5) - NB2PW;
-        const unsigned wa = g2_lds_addr(slot + (2 * ls0 + half) * M2 + blk0 * 32 + l32);
-        auto rd2 = [&](auto ss) __attribute__((always_inline)) {
-          constexpr int s = decltype(ss)::value;
-          g2_ds_read<2 * s * G2_BN * 4>(B[s], ua);
-          g2_ds_read<(2 * s * M2) * 4>(A[s][0], wa);
-          if constexpr (NB2PW > 1) g2_ds_read<(2 * s * M2 + 32) * 4>(A[s][1], wa);
-          if constexpr (NB2PW > 2) g2_ds_read<(2 * s * M2 + 64) * 4>(A[s][2], wa);
-        };
-        rd2(std::integral_constant<int, 0>{});
-        rd2(std::integral_constant<int, 1>{});
-        rd2(std::integral_constant<int, 2>{});
-        rd2(std::integral_constant<int, 3>{});
+  // ================================================================================================== consumers
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int l32 = lane & 31, half = lane >> 5;
+  g2_f32x16 acc2[NB2PW];
+  auto zero_acc2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if constexpr (NB2PW == 3) {
-            if (s == 0) g2_wait4<12>(B[0], A[0][0], A[0][1], A[0][2]);
-            else if (s == 1) g2_wait4<8>(B[1], A[1][0], A[1][1], A[1][2]);
-            else if (s == 2) g2_wait4<4>(B[2], A[2][0], A[2][1], A[2][2]);
-            else g2_wait4<0>(B[3], A[3][0], A[3][1], A[3][2]);
-          } else {
-            if (s == 0) g2_wait3<9>(B[0], A[0][0], A[0][1]);
-            else if (s == 1) g2_wait3<6>(B[1], A[1][0], A[1][1]);
-            else if (s == 2) g2_wait3<3>(B[2], A[2][0], A[2][1]);
-            else g2_wait3<0>(B[3], A[3][0], A[3][1]);
-          }
+    for (int i = 0; i < NB2PW; ++i)
 #pragma unroll
-          for (int i = 0; i < NB2PW; ++i)
-            if (i < nblk) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i], B[s], acc2[i], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
+  };
+  if constexpr (MULTI) zero_acc2();
+  G2_STAMP(2);
+
+  int n = 0;   // chunk sequence number
+  // phase 2 of one part: acc2 += W2[rows of the part] x activations (U).
+  // Software pipeline over "sub-chunks" of 4 k-steps (one per chunk at M2 = 384, two at M2 = 192): the fragments of
+  // sub-chunk k + 1 are requested in the MIDDLE of sub-chunk k's MFMAs (two register sets), right behind the barrier
+  // that says its chunk has landed, so neither the LDS round trip nor the barrier sits between two MFMA groups.  The
+  // barrier's own lgkmcnt(0) retires the current set's remaining reads (issued a whole sub-chunk earlier).
+  auto phase2 = [&]() __attribute__((always_inline)) {
+    // a wave whose blocks lie past M2 (the fourth wave when M2 = 192) works on the last NB2PW blocks instead -- reads in
+    // range, results never stored -- so every wave runs the same instruction stream
+    const int blk0 = (M2 >> 5) - w4 * NB2PW > 0 ? w4 * NB2PW : (M2 >> 5) - NB2PW;
+    constexpr int nst = KC2 >> 2;                 // steps per group and chunk: KC2 / 2 steps split in two (4 or 8)
+    constexpr int SPC = nst / 4;                  // sub-chunks per chunk (1 or 2)
+    constexpr int NSUB = NP2 * SPC;
+    static_assert(NSUB % 2 == 0, "the pipeline is unrolled by two");
+    float A0[4][NB2PW], B0[4], A1[4][NB2PW], B1[4];
+    auto rd2 = [&](float (&A)[4][NB2PW], float (&B)[4], int k) __attribute__((always_inline)) {
+      // sub-chunk k: chunk c = k / SPC (slot of sequence number n0 + c), steps ls0 .. ls0 + 3 inside the chunk (ls0 a
+      // multiple of 4): activation channels ka0 + 2 s + half with ka0 a multiple of 8 -> constant offsets between steps
+      const int c = k / SPC;
+      const float* const slot = ring + ((n + c) % G2_NSLOT) * G2_SLOT;
+      const int ls0 = grp * nst + (k % SPC) * 4;
+      const int ka0 = c * KC2 + 2 * ls0 + half;
+      const int urow0 = GATE ? ka0 + ((ka0 >> 5) << 5) : ka0;
+      const unsigned ua = g2_lds_addr(U + urow0 * G2_BN + l32);
+      const unsigned wa = g2_lds_addr(slot + (2 * ls0 + half) * M2 + blk0 * 32 + l32);
+      auto one = [&](auto ss) __attribute__((always_inline)) {
+        constexpr int s = decltype(ss)::value;
+        g2_ds_read<2 * s * G2_BN * 4>(B[s], ua);
+        g2_ds_read<(2 * s * M2) * 4>(A[s][0], wa);
+        if constexpr (NB2PW > 1) g2_ds_read<(2 * s * M2 + 32) * 4>(A[s][1], wa);
+        if constexpr (NB2PW > 2) g2_ds_read<(2 * s * M2 + 64) * 4>(A[s][2], wa);
+      };
+      one(std::integral_constant<int, 0>{});
+      one(std::integral_constant<int, 1>{});
+      one(std::integral_constant<int, 2>{});
+      one(std::integral_constant<int, 3>{});
+    };
+    // MFMAs of steps S0, S0 + 1; WAIT: the set was requested last (counted waits), else it has been retired already
+    auto mm2 = [&](float (&A)[4][NB2PW], float (&B)[4], auto s0, auto waitflag) __attribute__((always_inline)) {
+      constexpr int S0 = decltype(s0)::value;
+      constexpr bool WAIT = decltype(waitflag)::value;
+#pragma unroll
+      for (int s = S0; s < S0 + 2; ++s) {
+        if constexpr (WAIT) {
+          if constexpr (NB2PW == 3) { if (s == 0) g2_wait4<12>(B[0], A[0][0], A[0][1], A[0][2]); else g2_wait4<8>(B[1], A[1][0], A[1][1], A[1][2]); }
+          else { if (s == 0) g2_wait3<9>(B[0], A[0][0], A[0][1]); else g2_wait3<6>(B[1], A[1][0], A[1][1]); }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB2PW; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i], B[s], acc2[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T2 = std::integral_constant<int, 2>;
+    g2_barrier();                                 // chunk n landed (and the activations are complete in U)
+    if (!G2_DBG(in, 2)) rd2(A0, B0, 0);
+    for (int k = 0; k < NSUB; k += 2) {
+      if (!G2_DBG(in, 2)) mm2(A0, B0, T0{}, std::true_type{});
+      if ((k + 1) % SPC == 0) g2_barrier(); else g2_wait_all();
+      if (!G2_DBG(in, 2)) { rd2(A1, B1, k + 1); mm2(A0, B0, T2{}, std::false_type{}); mm2(A1, B1, T0{}, std::true_type{}); }
+      if (k + 2 < NSUB) {
+        if ((k + 2) % SPC == 0) g2_barrier(); else g2_wait_all();
+        if (!G2_DBG(in, 2)) rd2(A0, B0, k + 2);
+      }
+      if (!G2_DBG(in, 2)) mm2(A1, B1, T2{}, std::false_type{});
     }
-  }
+    n += NP2;
   };
 
   for (int part = 0;; ++part) {
     // ================================================================ phase 1
-    if (!producer) {
+    {
+      g2_f32x16 acc1[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[i][r] = 0.0f;
-    }
-    for (int c = 0; c < NP1; ++c, ++n) {
-      if (producer) {
-        if (n + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G2_IPC) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      g2_barrier();                               // chunk n is in LDS; every consumer is done with chunk n - 1
-      if (producer) {
-        if (n + 2 < NCH && !G2_DBG(in, 1)) issue(n + 2);
-      } else if (!G2_DBG(in, 2)) {
-        const float* const slot = ring + (n % G2_NSLOT) * G2_SLOT;
-        // this group's 4 steps: 8 c + 4 grp + s
-        int st = 8 * c + 4 * grp;
-        int cp = st / K1, j = st - cp * K1;
-        float A[4][3], B[4];
+      // this group's first k-step of the part is 4 grp: (channel pair, tap) -> window offset 2 cp xp + j dil, kept as
+      // SCALARS and advanced step by step (a division or a vector select here would be VALU work inside the loop)
+      int c_j = __builtin_amdgcn_readfirstlane((4 * grp) % K1);
+      int c_off = __builtin_amdgcn_readfirstlane(2 * ((4 * grp) / K1) * P.xp + c_j * in.dil);
+      const int wrap = 2 * P.xp - (K1 - 1) * in.dil;   // offset step from (cp, K1 - 1) to (cp + 1, 0)
+      auto next_step = [&]() __attribute__((always_inline)) {
+        const bool w = c_j + 1 == K1;
+        c_off += w ? wrap : in.dil;
+        c_j = w ? 0 : c_j + 1;
+      };
+      const unsigned xa = g2_lds_addr(xwin + half * P.xp + l32 + (P.a0 - in.pad));
+      // same software pipeline as phase 2: chunk c + 1's fragments are requested in the middle of chunk c's MFMAs
+      float A0[4][3], B0[4], A1[4][3], B1[4];
+      auto rd1 = [&](float (&A)[4][3], float (&B)[4], int c) __attribute__((always_inline)) {
+        const float* const slot = ring + ((n + c) % G2_NSLOT) * G2_SLOT;
         const unsigned sa = g2_lds_addr(slot + (8 * grp + half) * G2_R1 + w4 * 96 + l32);
-        const unsigned xa = g2_lds_addr(xwin + half * P.xp + l32 + (P.a0 - in.pad));
-        auto rd1 = [&](auto ss) __attribute__((always_inline)) {
+        auto one = [&](auto ss) __attribute__((always_inline)) {
           constexpr int s = decltype(ss)::value;
-          g2_ds_read<0>(B[s], xa + 4u * (unsigned)(2 * cp * P.xp + j * in.dil));
+          g2_ds_read<0>(B[s], xa + 4u * (unsigned)c_off);
           g2_ds_read<(2 * s * G2_R1) * 4>(A[s][0], sa);
           g2_ds_read<(2 * s * G2_R1 + 32) * 4>(A[s][1], sa);
           g2_ds_read<(2 * s * G2_R1 + 64) * 4>(A[s][2], sa);
-          if (++j == K1) { j = 0; ++cp; }
+          next_step();
         };
-        rd1(std::integral_constant<int, 0>{});
-        rd1(std::integral_constant<int, 1>{});
-        rd1(std::integral_constant<int, 2>{});
-        rd1(std::integral_constant<int, 3>{});
-        const int nval = nstep1 - st;             // steps of this group that exist (the last chunk may be short)
+        one(std::integral_constant<int, 0>{});
+        one(std::integral_constant<int, 1>{});
+        one(std::integral_constant<int, 2>{});
+        one(std::integral_constant<int, 3>{});
+        // the other group's 4 steps lie between this chunk's and the next one's
+        next_step();
+        next_step();
+        next_step();
+        next_step();
+      };
+      auto mm1 = [&](float (&A)[4][3], float (&B)[4], auto s0, auto waitflag) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(s0)::value;
+        constexpr bool WAIT = decltype(waitflag)::value;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (s == 0) g2_wait4<12>(B[0], A[0][0], A[0][1], A[0][2]);
-          else if (s == 1) g2_wait4<8>(B[1], A[1][0], A[1][1], A[1][2]);
-          else if (s == 2) g2_wait4<4>(B[2], A[2][0], A[2][1], A[2][2]);
-          else g2_wait4<0>(B[3], A[3][0], A[3][1], A[3][2]);
-          if (s < nval) {
+        for (int s = S0; s < S0 + 2; ++s) {
+          if constexpr (WAIT) { if (s == 0) g2_wait4<12>(B[0], A[0][0], A[0][1], A[0][2]); else g2_wait4<8>(B[1], A[1][0], A[1][1], A[1][2]); }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i], B[s], acc1[i], 0, 0, 0);
+          for (int i = 0; i < 3; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i], B[s], acc1[i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      using T0 = std::integral_constant<int, 0>;
+      using T2 = std::integral_constant<int, 2>;
+      g2_barrier();                               // chunk n landed
+      if (!G2_DBG(in, 2)) rd1(A0, B0, 0);
+      for (int c = 0; c < NP1; c += 2) {          // NP1 is even (host check)
+        if (!G2_DBG(in, 2)) mm1(A0, B0, T0{}, std::true_type{});
+        g2_barrier();                             // chunk n + c + 1 landed; A0 / B0 fully in registers (lgkmcnt(0))
+        if (!G2_DBG(in, 2)) { rd1(A1, B1, c + 1); mm1(A0, B0, T2{}, std::false_type{}); mm1(A1, B1, T0{}, std::true_type{}); }
+        if (c + 2 < NP1) {
+          g2_barrier();
+          if (!G2_DBG(in, 2)) rd1(A0, B0, c + 2);
+        }
+        if (!G2_DBG(in, 2)) mm1(A1, B1, T2{}, std::false_type{});
+      }
+      n += NP1;
+      G2_STAMP(3);
+      // ============================================================== combine the K-groups, bias, gate -> U
+      // U through a pointer the compiler cannot see through, re-made every part: otherwise it hoists the ~200 loop-
+      // invariant LDS addresses of this section out of the part loop and keeps them in scratch.
+      unsigned ub = g2_lds_addr(U), tb = g2_lds_addr(tab1);
+      asm volatile("" : "+v"(ub), "+v"(tb));
+      typedef __attribute__((address_space(3))) float lds_f32;
+      lds_f32* const Ul = reinterpret_cast<lds_f32*>(static_cast<uintptr_t>(ub));
+      const lds_f32* const T1l = reinterpret_cast<const lds_f32*>(static_cast<uintptr_t>(tb));
+      g2_barrier();                               // every consumer is done with phase 1
+      if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Ul[(w4 * 96 + i * 32 + HSP_ACC_ROW_G2(r, half)) * G2_BN + l32] = acc1[i][r];
+      }
+      g2_barrier();
+      if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = w4 * 96 + i * 32 + HSP_ACC_ROW_G2(r, half);    // packed phase-1 row inside the part
+            Ul[m * G2_BN + l32] = acc1[i][r] + Ul[m * G2_BN + l32] + T1l[part * G2_R1 + m];
           }
         }
       }
-    }
-    // ================================================================ combine the K-groups, bias, gate -> U
-    // U through a pointer the compiler cannot see through, re-made every part: otherwise it hoists the ~200 loop-
-    // invariant LDS addresses of this section out of the part loop and keeps them in scratch (a reload + vmcnt(0)
-    // per accumulator element: tens of microseconds per launch).
-    unsigned ub = g2_lds_addr(U), tb = g2_lds_addr(tab1);
-    asm volatile("" : "+v"(ub), "+v"(tb));
-    typedef __attribute__((address_space(3))) float lds_f32;
-    lds_f32* const Ul = reinterpret_cast<lds_f32*>(static_cast<uintptr_t>(ub));
-    const lds_f32* const T1l = reinterpret_cast<const lds_f32*>(static_cast<uintptr_t>(tb));
-    g2_barrier();                                 // every consumer is done with phase 1
-    if (!producer && grp == 1) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Ul[(w4 * 96 + i * 32 + HSP_ACC_ROW_G2(r, half)) * G2_BN + l32] = acc1[i][r];
-    }
-    g2_barrier();
-    if (!producer && grp == 0) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = w4 * 96 + i * 32 + HSP_ACC_ROW_G2(r, half);      // packed phase-1 row inside the part
-          const float v = acc1[i][r] + Ul[m * G2_BN + l32] + T1l[part * G2_R1 + m];
-          Ul[m * G2_BN + l32] = v;
+      g2_barrier();
+      {
+        const int tid = threadIdx.x;              // 0 .. 511
+        if (GATE) {
+          for (int idx = tid; idx < CP * G2_BN; idx += 64 * G2_NCW) {
+            const int c = idx >> 5, nn = idx & 31;
+            const int ra = ((c >> 5) << 6) + (c & 31);                   // a-row of channel c; its b-row is 32 below
+            const float va = Ul[ra * G2_BN + nn], vb = Ul[(ra + 32) * G2_BN + nn];
+            Ul[ra * G2_BN + nn] = hsp_tanh(va) * hsp_sigmoid(vb);
+          }
+        } else {
+          for (int idx = tid; idx < CP * G2_BN; idx += 64 * G2_NCW) Ul[idx] = hsp_apply_act(Ul[idx], in.act);
         }
       }
-    }
-    g2_barrier();
-    if (!producer) {
-      const int tid = threadIdx.x;                // 0 .. 511
-      if (GATE) {
-        for (int idx = tid; idx < CP * G2_BN; idx += 64 * G2_NCW) {
-          const int c = idx >> 5, nn = idx & 31;
-          const int ra = ((c >> 5) << 6) + (c & 31);                     // a-row of channel c; its b-row is 32 below
-          const float va = Ul[ra * G2_BN + nn], vb = Ul[(ra + 32) * G2_BN + nn];
-          Ul[ra * G2_BN + nn] = hsp_tanh(va) * hsp_sigmoid(vb);
-        }
-      } else {
-        for (int idx = tid; idx < CP * G2_BN; idx += 64 * G2_NCW) Ul[idx] = hsp_apply_act(Ul[idx], in.act);
-      }
+      G2_STAMP(4);
     }
     // ================================================================ phase 2 (the last part's runs after the loop)
     if (part == nparts - 1) break;
-    phase2(part);
+    phase2();
   }
 
-  if (!producer) {
-      // the epilogue's per-element operands (residual, running sum) and this lane's mask value: requested now, they
-    // arrive under the last phase 2.  Group g owns accumulator registers [8 g, 8 g + 8) of its blocks.
+  // epilogue operands, requested now (acc1's registers are free), they arrive under the last phase 2: the residual OR
+  // the running sum of an output element (the host refuses to fuse a layer that has both on the same rows), and this
+  // lane's mask value.  Group g owns accumulator registers [8 g, 8 g + 8) of its blocks.
+  float eop[NB2PW][8], emk[NB2PW];
+  {
     int tcl = t0 + l32 < in.Lin ? t0 + l32 : in.Lin - 1;
-    asm volatile("" : "+v"(tcl));                  // opaque: keeps the address arithmetic below inside this block
 #pragma unroll
     for (int i = 0; i < NB2PW; ++i) {
       const int mblk = (w4 * NB2PW + i) * 32;
@@ -451,17 +516,14 @@ __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_a
         if (o.mask_mode != HSP_MASK_NONE) emk[i] = o.mask[(int64_t)b * o.mask_bs + tcl];
       }
     }
-    }
-
+  }
+  G2_STAMP(5);
   if constexpr (!MULTI) zero_acc2();
-  phase2(nparts - 1);
+  phase2();
+  G2_STAMP(6);
 
   // ==================================================================== exchange halves, epilogue
   g2_barrier();                                   // every consumer is done with U and the ring
-  if (producer) {
-    g2_barrier();
-    return;
-  }
   // group g finalises accumulator registers [8 g, 8 g + 8) of its blocks and hands the other eight to its partner
   float* const xch = U;                           // [dst group][w4][NB2PW][8][64]
   {
@@ -499,6 +561,7 @@ __global__ __launch_bounds__(G2_THREADS, 3) void gemm2_kernel(const hsp_conv1d_a
       o.y[(int64_t)b * o.y_bs + (int64_t)co * o.y_cs + t] = v * o.post_scale;
     }
   }
+  G2_STAMP(7);
 }
 
 bool g2_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -557,6 +620,7 @@ int hsp_gemm2_try(const hsp_conv1d_args& in, const hsp_conv1d_args& o1, const hs
     acts = in.M;
   }
   if (in.w_ld < nparts * G2_R1 || nparts > G2_MAXPARTS) return -1;
+  if (((in.Cin >> 1) * in.K) & 15) return -1;     // phase 1 runs in whole chunks of 8 k-steps, an even number of them
   if (!g2_consumes(in, o1, acts)) return -1;
   int split = 0, M2 = o1.Cout;
   if (o2) {

@@ -26,20 +26,25 @@ hip_layers.finalize(wn, dev)
 x = torch.randn(a.batch, 192, a.frames, device=dev)
 mask = torch.ones(a.batch, 1, a.frames, device=dev)
 g = torch.randn(a.batch, 256, 1, device=dev)
-for _ in range(10):
+for _ in range(3):
     wn(x, mask, g=g)
 torch.cuda.synchronize()
 for rep in range(2):            # twice: the first pass over the variants also warms the clocks
     for dbg in a.debug:
         hip_layers.DEBUG_FLAGS = dbg
-        for _ in range(3):
+        wn(x, mask, g=g)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()          # replayed: the eager loop is bound by Python (~100 us per layer)
+        with torch.cuda.graph(graph):
             wn(x, mask, g=g)
+        for _ in range(3):
+            graph.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.reps):
-            wn(x, mask, g=g)
+            graph.replay()
         e1.record()
         torch.cuda.synchronize()
         print(f"pass {rep} WN H192 x8 B {a.batch} T {a.frames} debug {dbg}: {e0.elapsed_time(e1) / a.reps * 1e3:9.1f} us per forward "
-              f"({e0.elapsed_time(e1) / a.reps / 8 * 1e3:6.1f} us per layer)", flush=True)
+              f"({e0.elapsed_time(e1) / a.reps / 8 * 1e3:6.1f} us per layer incl. cond / mask launches)", flush=True)
