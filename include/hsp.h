@@ -276,6 +276,16 @@ int hsp_lstm_bidir_f32(const float* xproj, int64_t xp_bs, const float* whh_t, co
  * zeroes the padding / sums. */
 int hsp_duration_f32(const float* logw, int64_t lw_bs, const int64_t* lengths, float length_scale, float* dur,
                      int64_t d_bs, float* frames, int32_t B, int32_t N, void* stream);
+/* y[b, c, t] = max_{j < k} x[b, c, k t + j], t < L / k : nn.MaxPool1d(kernel_size = 8, stride = 8) of the legacy
+ * prosody path (ttv_v1/t2w2v_transformer.py:795,1046).  y contiguous [B, C, L / k]. */
+int hsp_maxpool1d_f32(const float* x, int64_t x_bs, int64_t x_cs, float* y, int32_t B, int32_t C, int32_t L,
+                      int32_t k, void* stream);
+/* codes[b, rep t + r] = argmax_e -(|x_t|^2 - 2 x_t . embed[e] + |embed[e]|^2) for r < rep and rep t + r < Tout:
+ * EuclideanCodebook.quantize (ttv_v1/core_vq.py:175-183; first maximum on ties) followed by the "repeat every
+ * pooled frame `stride` times, cut to the mel length" of ttv_v1/t2w2v_transformer.py:1051-1052.
+ * x [B, D, T] with strides (x_bs, x_cs, 1), embed [bins, D], codes int64 rows of stride c_bs. */
+int hsp_vq_nearest_f32(const float* x, int64_t x_bs, int64_t x_cs, const float* embed, int64_t* codes, int64_t c_bs,
+                       int32_t B, int32_t D, int32_t T, int32_t bins, int32_t rep, int32_t Tout, void* stream);
 /* GaussianUpsampling.forward (ttv_v1/Gaussian.py:35-69) with the range clamp
  * min(range, 2 dur), max(., 1e-5) of ttv_v1/t2w2v_transformer.py:961-963: x [B, C, N] (strides x_bs, x_cs, 1)
  * -> out [B, C, T] contiguous, frames t >= frames[b] zero. */

@@ -91,6 +91,9 @@ SIGNATURES = {
     "hsp_duration_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_float, _fp, C.c_int64, _fp, C.c_int32, C.c_int32, _fp]),
     "hsp_gaussian_upsample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp,
                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_maxpool1d_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_vq_nearest_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_add_cbias_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_zero_below_f32": (C.c_int, [_fp, C.c_float, _fp, C.c_int64, _fp]),
     "hsp_peak_int16": (C.c_int, [_fp, C.c_int64, _fp, C.c_float, _fp, C.c_int64, C.c_int32, C.c_int64, _fp]),

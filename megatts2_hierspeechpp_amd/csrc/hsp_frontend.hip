@@ -233,6 +233,50 @@ __global__ __launch_bounds__(1024) void peak_int16_kernel(const float* __restric
   }
 }
 
+
+// ---- legacy (non-PLM) prosody path of SynthesizerTrn.infer: MaxPool1d(k, stride k) and the nearest-code search of
+//      the prompt's 20-dim prosody track (ttv_v1/t2w2v_transformer.py:1041-1054, core_vq.py:175-183)
+__global__ void maxpool1d_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs, float* __restrict__ y, int B,
+                                 int C, int Lout, int k) {
+  const int64_t n = (int64_t)B * C * Lout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Lout);
+    const int c = (int)((i / Lout) % C);
+    const int b = (int)(i / ((int64_t)Lout * C));
+    const float* p = x + (int64_t)b * x_bs + (int64_t)c * x_cs + (int64_t)t * k;
+    float m = p[0];
+    for (int j = 1; j < k; ++j) m = fmaxf(m, p[j]);
+    y[i] = m;
+  }
+}
+
+// one thread per (b, t): dist[e] = -(|x|^2 - 2 x.e + |e|^2) as core_vq.py:177-181 writes it, first maximum wins
+// (torch.max's tie rule); the code is written `rep` times: codes[b, rep t + r], r < rep, while rep t + r < Tout
+__global__ void vq_nearest_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs, const float* __restrict__ embed,
+                                  int64_t* __restrict__ codes, int64_t c_bs, int B, int D, int T, int bins, int rep,
+                                  int Tout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int b = i / T, t = i - b * T;
+  const float* xp = x + (int64_t)b * x_bs + t;
+  float xx = 0.0f;
+  for (int d = 0; d < D; ++d) xx = fmaf(xp[(int64_t)d * x_cs], xp[(int64_t)d * x_cs], xx);
+  float best = -INFINITY;
+  int arg = 0;
+  for (int e = 0; e < bins; ++e) {
+    const float* ep = embed + (int64_t)e * D;
+    float xe = 0.0f, ee = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      xe = fmaf(xp[(int64_t)d * x_cs], ep[d], xe);
+      ee = fmaf(ep[d], ep[d], ee);
+    }
+    const float dist = -((xx - 2.0f * xe) + ee);
+    if (dist > best) { best = dist; arg = e; }
+  }
+  for (int r = 0; r < rep; ++r)
+    if (rep * t + r < Tout) codes[(int64_t)b * c_bs + rep * t + r] = arg;
+}
+
 }  // namespace
 
 #define HSP_STREAM static_cast<hipStream_t>(stream)
@@ -302,5 +346,26 @@ extern "C" int hsp_peak_int16(const float* x, int64_t x_bs, const int64_t* lengt
                               int64_t o_bs, int32_t B, int64_t n, void* stream) {
   if (!x || !out || B <= 0 || n <= 0) return HSP_EINVAL;
   hipLaunchKernelGGL(peak_int16_kernel, dim3((unsigned)B), dim3(1024), 0, HSP_STREAM, x, x_bs, lengths, gain, out, o_bs, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_maxpool1d_f32(const float* x, int64_t x_bs, int64_t x_cs, float* y, int32_t B, int32_t C, int32_t L,
+                                 int32_t k, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || L <= 0 || k <= 0 || L / k <= 0) return HSP_EINVAL;
+  const int Lout = L / k;                      // torch MaxPool1d(kernel_size = stride = k), floor mode
+  int64_t blocks = ((int64_t)B * C * Lout + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool1d_kernel, dim3((unsigned)blocks), dim3(256), 0, HSP_STREAM, x, x_bs, x_cs, y, B, C, Lout, k);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_vq_nearest_f32(const float* x, int64_t x_bs, int64_t x_cs, const float* embed, int64_t* codes,
+                                  int64_t c_bs, int32_t B, int32_t D, int32_t T, int32_t bins, int32_t rep, int32_t Tout,
+                                  void* stream) {
+  if (!x || !embed || !codes || B <= 0 || D <= 0 || T <= 0 || bins <= 0 || rep <= 0 || Tout <= 0 || Tout > rep * T)
+    return HSP_EINVAL;
+  const int blocks = (B * T + 63) / 64;
+  hipLaunchKernelGGL(vq_nearest_kernel, dim3((unsigned)blocks), dim3(64), 0, HSP_STREAM, x, x_bs, x_cs, embed, codes, c_bs, B,
+                     D, T, bins, rep, Tout);
   return (int)hipGetLastError();
 }

@@ -252,10 +252,25 @@ class PitchPredictor(nn.Module):
         return self.conv_post(x, lrelu=0.01)   # F.leaky_relu default slope (:458)
 
 
+class PLMConv(nn.Module):
+    """t2w2v_transformer.PLMConv (:517-528): x -> conv2(conv1(x * m) * m) * m on the 20-channel prosody track."""
+
+    def __init__(self, hidden_channels=80):
+        super().__init__()
+        self.conv1 = Conv1d(hidden_channels, hidden_channels, 5, padding=2)
+        self.conv2 = Conv1d(hidden_channels, hidden_channels, 5, padding=2)
+
+    def forward(self, x, mask, premasked=False):
+        if not premasked:
+            x = Fh.mask_mul(x, mask)
+        h = self.conv1(x, mask=mask, mask_mode=L.MASK_POST, force_direct=True)
+        return self.conv2(h, mask=mask, mask_mode=L.MASK_POST, force_direct=True)
+
+
 class SynthesizerTrn(nn.Module):
-    """t2w2v_transformer.SynthesizerTrn (:721-994), inference members only
-    (``inf_extract_tc_latent``, ``inf_plm_gen``).  Same constructor signature; sub-modules that only the
-    training ``forward`` touches (``lr``, ``plm_conv1/2``, ``vq_pooling``) are not built, so reference
+    """t2w2v_transformer.SynthesizerTrn (:721-1077), inference members only
+    (``inf_extract_tc_latent``, ``inf_plm_gen`` and the older non-PLM ``infer``).  Same constructor signature;
+    the ``lr`` sub-module, which only the training ``forward`` touches, is not built, so reference
     checkpoints load with ``strict=False``.
 
     The reference front-end is B = 1 only (RangePredictor's ``.squeeze()`` and the [B,1,N] x [B,N]
@@ -287,9 +302,13 @@ class SynthesizerTrn(nn.Module):
         self.pp = PitchPredictor()
         self.quantizer = ResidualVectorQuantizer(dimension=20, n_q=1, bins=1024)
         self.ssl_proj = Conv1d(20, ic, 1)
+        # legacy (non-PLM) prosody path of infer(): the prompt mel's first 20 bins -> PLMConv -> max-pool 8 -> PLMConv
+        # -> nearest code (:794-797); nn.MaxPool1d has no parameters
+        self.plm_conv1 = PLMConv(hidden_channels=20)
+        self.plm_conv2 = PLMConv(hidden_channels=20)
 
     # keys of the reference checkpoint that no inference path reads
-    UNUSED = ("lr.", "plm_conv1.", "plm_conv2.", "enc_p.cond.", "enc_p.proj.", "w2v_encoder.project.", "w2v_encoder.proj.")
+    UNUSED = ("lr.", "enc_p.cond.", "enc_p.proj.", "w2v_encoder.project.", "w2v_encoder.proj.")
     UNUSED_LEAVES = ("_codebook.inited", "_codebook.cluster_size", "_codebook.embed_avg")
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -356,3 +375,78 @@ class SynthesizerTrn(nn.Module):
         lf0 = self.pp(w2v_pred, g, lengths=len2)
         mask4 = Fh.sequence_mask(4 * len2, 4 * T2)
         return w2v_pred, Fh.mask_mul(lf0, mask4).squeeze(1)
+
+    @torch.no_grad()
+    def infer(self, x, x_lengths, mel_spk, mel_spk_lengths, tone, language, dur=None, mrte_mel=None, mrte_mel_lengths=None,
+              noise_scale=1, noise_scale_w=1, length_scale=1, denoise_ratio=0):
+        """The older non-PLM text -> (w2v, lf0) path (:996-1077; call site inference.py:158): the prosody codes come
+        from the PROMPT mel (first 20 bins -> PLMConv -> max-pool 8 -> PLMConv -> nearest code of the 1024-entry
+        codebook, every code held for 8 frames) instead of from the prosody LM.
+
+        The reference adds the projected codes, one per prompt-mel frame, to the text-derived frames (:1057), so it
+        only runs when the caller passes ``dur`` [B, N] with sum(dur) / 2 == mel_spk.shape[2] (its RangePredictor call
+        also needs ``dur`` 2-D) and the mel length is a multiple of 8 (:999); the same holds here, anything else raises.
+        ``x_lengths`` of the encoder come from the PREDICTED durations (:1031-1035), as in the reference.  ``mrte_mel``
+        is accepted and -- as in the reference, which overwrites g at :1009 -- does not change the style vector.
+        B = 1 (the reference's RangePredictor .squeeze()); a batch here is B independent utterances."""
+        if dur is None:
+            raise L.HspError("infer(): the reference path needs explicit durations (dur [B, N]); see the docstring")
+        B, N = x.shape
+        C = self.inter_channels
+        Tm = mel_spk.shape[2]
+        if Tm % self.stride:
+            raise L.HspError("infer(): the prompt mel length must be a multiple of 8 (sequence_mask(len / 8, T / 8))")
+        x_lengths = x_lengths.to(torch.int64)
+        mel_mask = Fh.sequence_mask(mel_spk_lengths, Tm)
+        g = self.emb_g(mel_spk, mel_mask, per_utterance=True).unsqueeze(-1)
+        h, x_mask = self.enc_p(x, x_lengths, g, tone, language)
+        ref_mel, ref_len = (mrte_mel, mrte_mel_lengths) if mrte_mel is not None else (mel_spk, mel_spk_lengths)
+        mel_out, h_mask = self.mel_encoder(ref_mel, ref_len)
+        xd = torch.empty(B, C + 1, N, dtype=torch.float32, device=x.device)
+        xs = xd[:, :C]
+        self.mha(h, mel_out, mask_q=x_mask, mask_k=h_mask, res=h, cbias=self.cond_g(g, force_direct=True), out=xs)
+        # predicted durations: only their sum is used (the encoder's lengths); the frames follow the caller's `dur`
+        logw = self.duration_predictor(xs, x_mask, g=g, lengths=x_lengths)
+        dpred = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        frames_pred = torch.empty(B, dtype=torch.float32, device=x.device)
+        L.check(L.lib().hsp_duration_f32(L.fptr(logw), logw.stride(0), L.ptr(x_lengths), 1.0, L.fptr(dpred), dpred.stride(0),
+                                         L.fptr(frames_pred), B, N, L.stream_ptr()), "hsp_duration_f32")
+        dcol = xd[:, C]
+        dcol.copy_(dur.reshape(B, N).to(torch.float32))
+        frames = torch.empty(B, dtype=torch.float32, device=x.device)
+        L.check(L.lib().hsp_duration_f32(None, 0, L.ptr(x_lengths), 1.0, L.fptr(dcol), dcol.stride(0), L.fptr(frames), B, N,
+                                         L.stream_ptr()), "hsp_duration_f32")
+        rng = self.RangePredictor(xd, x_lengths)
+        frames_h = frames.cpu()
+        T = int(frames_h.max().item())
+        T2 = (T - 1) // 2 + 1
+        if T2 != Tm:
+            raise L.HspError(f"infer(): sum(dur) / 2 = {T2} frames but the prompt mel has {Tm}: the reference adds the "
+                             "two tensors frame by frame (t2w2v_transformer.py:1057)")
+        x_frame = self.gaussian(xs, dcol, rng, x_lengths, frames, T)
+        x_frame = self.dur_downsample(x_frame[:, :, ::2])
+        # prosody codes of the prompt
+        q_in = self.plm_conv1(mel_spk[:, :20], mel_mask)
+        pooled = torch.empty(B, 20, Tm // self.stride, dtype=torch.float32, device=x.device)
+        L.check(L.lib().hsp_maxpool1d_f32(L.fptr(q_in), q_in.stride(0), q_in.stride(1), L.fptr(pooled), B, 20, Tm, self.stride,
+                                          L.stream_ptr()), "hsp_maxpool1d_f32")
+        pool_len = torch.div(mel_spk_lengths.to(torch.int64) + self.stride - 1, self.stride, rounding_mode="floor")
+        pool_mask = Fh.sequence_mask(pool_len, Tm // self.stride)   # t < len / 8 (float compare) == t < ceil(len / 8)
+        q_in = self.plm_conv2(pooled, pool_mask)
+        codes = torch.empty(B, Tm, dtype=torch.int64, device=x.device)
+        cb = self.quantizer.vq.layers[0]._codebook
+        L.check(L.lib().hsp_vq_nearest_f32(L.fptr(q_in), q_in.stride(0), q_in.stride(1), L.fptr(cb._w), L.ptr(codes),
+                                           codes.stride(0), B, 20, Tm // self.stride, self.quantizer.bins, self.stride, Tm,
+                                           L.stream_ptr()), "hsp_vq_nearest_f32")
+        q = self.quantizer.decode(codes)
+        # x_frame + ssl_proj(q * mel_mask) * mel_mask [+ w2v_encoder.cond(g), fused]
+        xq = self.ssl_proj(Fh.mask_mul(q, mel_mask), mask=mel_mask, mask_mode=L.MASK_PRE, res=x_frame,
+                           cbias=None)
+        xq = Fh.add_cbias(xq, self.w2v_encoder.cond(g, force_direct=True))
+        enc_len = frames_pred / 2                                     # (:1031-1035) float, from the predicted durations
+        len2 = torch.clamp(torch.ceil(enc_len), max=T2).to(torch.int64)
+        y_mask = Fh.sequence_mask(len2, T2)
+        x2v_enc, _ = self.w2v_encoder(xq, enc_len, g, x_mask=y_mask, cond_added=True)
+        w2v_pred = self.w2v_decoder(x2v_enc, y_mask, g=g)
+        lf0 = self.pp(w2v_pred, g)
+        return w2v_pred, lf0.squeeze(1)

@@ -139,6 +139,15 @@ def run_oracle(meta, arrays):
         return [codes, logits]
     if kind == "speechsr":
         return [O.speechsr(sd, t("x"), meta["factor"], name + ".dec")]
+    if kind == "speechsr_real":   # the reference's shipped checkpoint travels inside the fixture ("w:" arrays)
+        real = {k[2:]: torch.from_numpy(v) for k, v in arrays.items() if k.startswith("w:")}
+        return [O.speechsr(real, t("x"), meta["factor"], "dec")]
+    if kind == "vc_plain":
+        return [O.synth_voice_conversion(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"), t("f0"),
+                                         meta["noise_scale"], t("noise"))]
+    if kind == "ttv_infer":
+        w2v, lf0, _ = O.ttv_infer_one(sd, t("ids"), t("mel"), t("tone"), t("language"), t("dur"))
+        return [w2v, lf0]
     raise KeyError(kind)
 
 
@@ -180,7 +189,7 @@ def build_module(meta):
     if kind == "generator":
         return H.Generator(192, cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"], cfg["upsample_rates"],
                            cfg["upsample_initial_channel"], cfg["upsample_kernel_sizes"], gin_channels=256)
-    if kind in ("infer", "vc"):
+    if kind in ("infer", "vc", "vc_plain"):
         return H.SynthesizerTrn(641, 61440 // 320, **cfg)
     if kind == "rel_mha":
         from megatts2_hierspeechpp_amd import attentions
@@ -194,10 +203,13 @@ def build_module(meta):
     if kind == "tts_e2e":
         from megatts2_hierspeechpp_amd.inference_plm import TtsModels
         return TtsModels(cfg, TTV_MODEL)
-    if kind in ("ttv_front", "ttv_gen"):
+    if kind in ("ttv_front", "ttv_gen", "ttv_infer"):
         from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import SynthesizerTrn as Text2W2V
         return Text2W2V(126, 11, 4, 641, 320, 16000, 60, **TTV_MODEL)
-    if kind == "speechsr":
+    if kind in ("speechsr", "speechsr_real"):
+        if meta["factor"] == 1.5:    # the 24 kHz model pins x1.5 whatever its config says (speechsr24k/speechsr.py:96)
+            from megatts2_hierspeechpp_amd.speechsr24k.speechsr import SynthesizerTrn as SR
+            return SR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [3], 32, [3])
         from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SR
         return SR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [meta["factor"]], 32, [3])
     raise KeyError(kind)
@@ -208,7 +220,17 @@ def run_hip(meta, arrays, device):
     from megatts2_hierspeechpp_amd import functional as Fh
     from megatts2_hierspeechpp_amd.hip_layers import finalize
     mod = build_module(meta)
-    mod.load_state_dict(synth_sd(meta), strict=True)
+    if meta["kind"] == "speechsr_real":
+        sd = {k[2:]: torch.from_numpy(v) for k, v in arrays.items() if k.startswith("w:")}
+    else:
+        sd = synth_sd(meta)
+        # parameters the fixture's path never reads (sub-modules of other entry points of the same class) keep the
+        # synthetic recipe too, so that the load stays strict
+        pre = meta["prefix"] + "." if meta["prefix"] else ""
+        for k, v in mod.state_dict().items():
+            if k not in sd:
+                sd[k] = torch.from_numpy(synth.synth_tensor(pre + k, tuple(v.shape), meta["seed"]))
+    mod.load_state_dict(sd, strict=True)
     finalize(mod, device)
     d = lambda k: torch.from_numpy(arrays[k]).to(device)
     kind = meta["kind"]
@@ -221,7 +243,7 @@ def run_hip(meta, arrays, device):
             kind, lambda: arrays["x"].shape[2])()
         mask = Fh.sequence_mask(d("lengths"), T)
     with torch.no_grad():
-        if kind in ("act1d", "amp_block", "convtr", "dblock", "speechsr"):
+        if kind in ("act1d", "amp_block", "convtr", "dblock", "speechsr", "speechsr_real"):
             out = [mod(d("x"))]
         elif kind == "wn":
             out = [mod(d("x"), mask, g=d("g"))]
@@ -242,6 +264,14 @@ def run_hip(meta, arrays, device):
             xf, g, fl, _ = mod.inf_extract_tc_latent(d("ids"), d("lengths"), d("mel"), d("mel_lengths"), d("tone"),
                                                      d("language"))
             out = [xf, g, fl]
+        elif kind == "ttv_infer":
+            n = arrays["ids"].shape[1]
+            dl = lambda v: torch.tensor(v, dtype=torch.int64, device=device)
+            out = list(mod.infer(d("ids"), dl([n]), d("mel"), dl([arrays["mel"].shape[2]]), d("tone"), d("language"),
+                                 dur=d("dur")))
+        elif kind == "vc_plain":
+            out = [mod.voice_conversion(d("w2v"), d("src_length"), d("mel"), d("trg_length"), d("f0"),
+                                        noise_scale=meta["noise_scale"], noise=d("noise"))]
         elif kind == "ttv_gen":
             out = list(mod.inf_plm_gen(d("x_frame"), d("g"), d("codes"), d("frame_lengths"), None))
         elif kind == "plm":

@@ -240,6 +240,24 @@ def ttv_cases():
              dict(x_frame=xf, g=g, codes=codes, frame_lengths=flen, lengths=np.array(t2s, np.int64)),
              [t(w2v), t(lf0)], [t(ow2v), t(olf0)])
 
+    # -- N3: the older non-PLM SynthesizerTrn.infer (:996-1077, call site inference.py:158).  The reference only runs with
+    #         explicit durations whose half-sum equals the prompt mel length, a multiple of 8 (the projected prompt
+    #         codes are added frame by frame to the text-derived frames).
+    infer_tops = front + gen + ("plm_conv1", "plm_conv2")
+    r_saved, r = r, np.random.default_rng(78)   # own stream: the fixtures below keep the ids they always had
+    for case, n, d, seed in [("ttv_infer_n8", 8, 10.0, 41), ("ttv_infer_n12", 12, 8.0, 42)]:
+        tm = int(n * d) // 2
+        ids = r.integers(1, 126, (1, n))
+        tone, lang = r.integers(0, 11, (1, n)), np.where(ids < 74, 1, np.where(ids < 113, 2, 0))
+        mel = synth.synth_inputs(1, tm, seed=seed)["mel"]
+        dur = np.full((1, n), d, np.float32)
+        w2v, lf0 = net.infer(t(ids), t(np.array([n])), t(mel), t(np.array([tm])), t(tone), t(lang), dur=t(dur))
+        ow2v, olf0, ocodes = O.ttv_infer_one(sd, t(ids), t(mel), t(tone), t(lang), t(dur))
+        print(case, "prompt codes", ocodes.flatten().tolist())
+        save(case, dict(kind="ttv_infer", prefix="", seed=W, shapes=pick(infer_tops)),
+             dict(ids=ids, tone=tone, language=lang, mel=mel, dur=dur), [w2v, lf0], [ow2v, olf0])
+    r = r_saved
+
     # -- A19: the tensor core of inference_plm.py:tts (:156-190) -- front-end -> PLM -> w2v/pitch ->
     #         pitch clipping -> voice_conversion_noise_control -> peak-normalised int16.  The call
     #         sequence below is what tts() runs between mel extraction and wav writing (both file /
@@ -462,6 +480,18 @@ def main():
         save(name, dict(kind="vc", prefix="", seed=W, shapes=used, noise_scale=0.333, denoise_ratio=0.3),
              dict(w2v=inp["w2v"], f0=f0_2d, mel=mel2, noise=inp["noise"], src_length=slen, trg_length=mlen), ref, orc)
 
+        # -- A14: plain voice_conversion (one style vector, no denoised prompt)
+        name = "vc_plain"
+        inp = synth.synth_inputs(1, 36, seed=95, mel_frames=44)
+        slen, mlen1 = np.array([36], np.int64), np.array([44], np.int64)
+        f0_2d = inp["f0"][:, 0]
+        with FixedNoise(t(inp["noise"])):
+            ref = net.voice_conversion(t(inp["w2v"]), t(slen), t(inp["mel"]), t(mlen1), t(f0_2d), noise_scale=0.333)
+        orc = O.synth_voice_conversion(sd, cfg, t(inp["w2v"]), t(slen), t(inp["mel"]), t(mlen1), t(f0_2d), 0.333,
+                                       t(inp["noise"]))
+        save(name, dict(kind="vc_plain", prefix="", seed=W, shapes=used, noise_scale=0.333),
+             dict(w2v=inp["w2v"], f0=f0_2d, mel=inp["mel"], noise=inp["noise"], src_length=slen, trg_length=mlen1), ref, orc)
+
         # -- A15: SpeechSR48 (synthetic weights; the real-checkpoint run is checked
         #         here against the oracle but the checkpoint itself is not committed)
         sys.path.insert(0, os.path.join(args.ref, "speechsr48k"))
@@ -480,6 +510,26 @@ def main():
         err = (net_sr(t(x)) - O.speechsr(real, t(x), 3, "dec")).abs().max().item()
         print(f"speechsr48 real checkpoint: oracle-vs-ref {err:.2e}")
         assert err < 1e-4
+
+        # -- N3: SpeechSR24 (speechsr24k/speechsr.py: the same network, interpolation x1.5).  Synthetic weights, and the
+        #        REAL shipped checkpoint G_340000.pth: its dec.* tensors (data, 0.43 M floats) travel inside the fixture
+        #        so that the GPU parity test runs on real weights.
+        sr24 = importlib.import_module("speechsr24k.speechsr")
+        mcfg24 = json.load(open(os.path.join(args.ref, "speechsr24k", "config.json")))["model"]
+        net24 = sr24.SynthesizerTrn(128, 9600 // 320, **mcfg24)
+        shapes, sd = load_synth(net24, W, "speechsr24.")
+        x24 = x[:, :, :2001]                       # odd length: int(L * 1.5) truncates
+        save("speechsr24", dict(kind="speechsr", prefix="speechsr24", seed=W, shapes=shapes, factor=1.5), dict(x=x24),
+             net24(t(x24)), O.speechsr(sd, t(x24), 1.5, "speechsr24.dec"))
+        ck = torch.load(os.path.join(args.ref, "speechsr24k", "G_340000.pth"), map_location="cpu", weights_only=False)
+        real = ck["model"] if "model" in ck else ck
+        net24.load_state_dict(real, strict=True)
+        dec = {k: v.float() for k, v in real.items() if k.startswith("dec.")}
+        arrays = {"x": x24}
+        arrays.update({"w:" + k: v.numpy() for k, v in dec.items()})
+        save("speechsr24_real", dict(kind="speechsr_real", prefix="", seed=W, shapes=[], factor=1.5,
+                                     checkpoint="speechsr24k/G_340000.pth (dec.* tensors stored in this fixture)"),
+             arrays, net24(t(x24)), O.speechsr(dec, t(x24), 1.5, "dec"))
 
 
 if __name__ == "__main__":
