@@ -53,7 +53,8 @@ enum {
   HSP_ACT_RELU = 3,      /* attentions.FFN, attentions.py:292 */
   HSP_ACT_MISH = 4,      /* StyleEncoder, styleencoder.py:9-10 */
   HSP_ACT_SILU = 5,      /* cond_block, hierspeechpp_speechsynthesizer.py:72 */
-  HSP_ACT_SOFTPLUS = 6
+  HSP_ACT_SOFTPLUS = 6,
+  HSP_ACT_GELU_ERF = 7   /* exact GELU x Phi(x) of the wav2vec2 producer (HF ACT2FN["gelu"]) */
 };
 
 /* how packed weight rows map to output channels */
@@ -165,6 +166,18 @@ int hsp_conv1d_direct_f32(const hsp_conv1d_args* a, void* stream);
 /* which kernel / tile configuration hsp_conv1d_mfma_f32 would pick: writes BM, BN, KC, LDS bytes
  * (KC = 0: the token-GEMM kernel) */
 int hsp_conv1d_mfma_plan(const hsp_conv1d_args* a, int32_t out4[4]);
+
+/* --------------------------------------- feature producer of inference_vc.py */
+/* y[i] = act(x[i]) (HSP_ACT_*): the GELU that follows the channel LayerNorm of every wav2vec2 feature-encoder
+ * layer (HF Wav2Vec2LayerNormConvLayer.forward: conv -> LayerNorm -> GELU). */
+int hsp_act_f32(const float* x, float* y, int64_t n, int32_t act, void* stream);
+/* y[b, t] = x[b, reflect(t - pad)], t < L + 2 pad : F.pad(audio, (40, 40), "reflect") at inference_vc.py:85.
+ * x rows of stride x_bs, y contiguous [B, L + 2 pad]; pad < L. */
+int hsp_reflect_pad_f32(const float* x, int64_t x_bs, float* y, int32_t B, int32_t L, int32_t pad, void* stream);
+/* F0 conversion of inference_vc.py:80-81,104-105: with V = {f0_src != 0}, W = {f0_trg != 0} (population statistics,
+ * numpy's default ddof = 0): out = log(max((f0_src - mean_V) / std_V * std_W + mean_W, 0) + 1) on V and log(1) = 0
+ * elsewhere.  One utterance per call (the statistics are per utterance): f0_src [n_src], f0_trg [n_trg]. */
+int hsp_f0_convert_f32(const float* f0_src, int32_t n_src, const float* f0_trg, int32_t n_trg, float* out, void* stream);
 
 /* ------------------------------------------------------- anti-aliased activation */
 /* y = DownSample2x(SnakeBeta(UpSample2x(x))): alias_free_torch/act.py:23-28,

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HSP_LIB", os.path.join(_HERE, "libhsp.so"))  # HSP_LI
 
 # enums of include/hsp.h
 PRO_NONE, PRO_LRELU, PRO_ACT1D, PRO_SILU = 0, 1, 2, 3
-ACT_NONE, ACT_TANH, ACT_GELU_TANH, ACT_RELU, ACT_MISH, ACT_SILU, ACT_SOFTPLUS = 0, 1, 2, 3, 4, 5, 6
+ACT_NONE, ACT_TANH, ACT_GELU_TANH, ACT_RELU, ACT_MISH, ACT_SILU, ACT_SOFTPLUS, ACT_GELU_ERF = 0, 1, 2, 3, 4, 5, 6, 7
 ROWS_PLAIN, ROWS_GATE_WN, ROWS_GATE_GLU, ROWS_SHUFFLE = 0, 1, 2, 3
 MASK_NONE, MASK_PRE, MASK_POST, MASK_BOTH = 0, 1, 2, 3
 EINVAL = -1
@@ -91,6 +91,9 @@ SIGNATURES = {
     "hsp_duration_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_float, _fp, C.c_int64, _fp, C.c_int32, C.c_int32, _fp]),
     "hsp_gaussian_upsample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp,
                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_act_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp]),
+    "hsp_reflect_pad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
+    "hsp_f0_convert_f32": (C.c_int, [_fp, C.c_int32, _fp, C.c_int32, _fp, _fp]),
     "hsp_maxpool1d_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_vq_nearest_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, _fp]),

@@ -48,6 +48,7 @@ __device__ __forceinline__ float hsp_apply_act(float v, int act) {
     }
     case HSP_ACT_SILU: return v * hsp_sigmoid(v);
     case HSP_ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(expf(v));
+    case HSP_ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.7071067811865476f));
     default: return v;
   }
 }

@@ -394,6 +394,64 @@ __global__ void linear_interp_kernel(const float* __restrict__ x, float* __restr
   }
 }
 
+__global__ void act_kernel(const float* x, float* y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = hsp_apply_act(x[i], act);
+}
+
+__global__ void reflect_pad_kernel(const float* x, int64_t x_bs, float* y, int B, int L, int pad) {
+  const int Lo = L + 2 * pad;
+  const int64_t n = (int64_t)B * Lo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / Lo), t = (int)(i - (int64_t)b * Lo) - pad;
+    const int s = t < 0 ? -t : (t >= L ? 2 * (L - 1) - t : t);
+    y[i] = x[(int64_t)b * x_bs + s];
+  }
+}
+
+// one workgroup: voiced statistics of both tracks in double (the reference's numpy float32 mean / std differ from the
+// exact values by ~1e-7 relative; double keeps this side at the exact ones), then the conversion
+__global__ __launch_bounds__(256) void f0_convert_kernel(const float* src, int ns, const float* trg, int nt, float* out) {
+  __shared__ double red[4][256];
+  __shared__ double stat[4];
+  double s1 = 0, c1 = 0, s2 = 0, c2 = 0;
+  for (int i = threadIdx.x; i < ns; i += 256) if (src[i] != 0.0f) { s1 += src[i]; c1 += 1; }
+  for (int i = threadIdx.x; i < nt; i += 256) if (trg[i] != 0.0f) { s2 += trg[i]; c2 += 1; }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = c1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = c2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  const double m1 = red[1][0] > 0 ? red[0][0] / red[1][0] : 0.0, m2 = red[3][0] > 0 ? red[2][0] / red[3][0] : 0.0;
+  const double n1 = red[1][0], n2 = red[3][0];
+  __syncthreads();
+  double v1 = 0, v2 = 0;
+  for (int i = threadIdx.x; i < ns; i += 256) if (src[i] != 0.0f) { const double d = src[i] - m1; v1 += d * d; }
+  for (int i = threadIdx.x; i < nt; i += 256) if (trg[i] != 0.0f) { const double d = trg[i] - m2; v2 += d * d; }
+  red[0][threadIdx.x] = v1; red[2][threadIdx.x] = v2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[2][threadIdx.x] += red[2][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stat[0] = m1; stat[1] = n1 > 0 ? sqrt(red[0][0] / n1) : 1.0; stat[2] = m2; stat[3] = n2 > 0 ? sqrt(red[2][0] / n2) : 0.0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ns; i += 256) {
+    float o = 0.0f;
+    if (src[i] != 0.0f) {
+      // the reference's steps, in float64 like its numpy arrays (get_yaapt_f0 works on float64), then the float32 cast
+      // of torch.FloatTensor(f0 + 1) and a float32 log
+      const double z = ((double)src[i] - stat[0]) / stat[1];
+      const double f = fmax(z * stat[3] + stat[2], 0.0);
+      o = logf((float)(f + 1.0));
+    }
+    out[i] = o;
+  }
+}
+
 __global__ void axpby_kernel(const float* x, const float* z, float* y, float a, float b, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + b * z[i];
@@ -605,6 +663,26 @@ extern "C" int hsp_linear_interp_f32(const float* x, float* y, int32_t B, int32_
   const float scale = (float)Lin / (float)Lout;  // torch: area_pixel_compute_scale, align_corners=False
   hipLaunchKernelGGL(linear_interp_kernel, dim3(grid_for((int64_t)B * C * Lout, 256)), dim3(256), 0, HSP_STREAM, x, y,
                      (int64_t)B * C, Lin, Lout, scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_act_f32(const float* x, float* y, int64_t n, int32_t act, void* stream) {
+  if (!x || !y || n <= 0 || act < 0 || act > HSP_ACT_GELU_ERF) return HSP_EINVAL;
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n, 256)), dim3(256), 0, HSP_STREAM, x, y, n, act);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_reflect_pad_f32(const float* x, int64_t x_bs, float* y, int32_t B, int32_t L, int32_t pad, void* stream) {
+  if (!x || !y || B <= 0 || L <= 0 || pad < 0 || pad >= L) return HSP_EINVAL;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for((int64_t)B * (L + 2 * pad), 256)), dim3(256), 0, HSP_STREAM, x, x_bs,
+                     y, B, L, pad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int hsp_f0_convert_f32(const float* f0_src, int32_t n_src, const float* f0_trg, int32_t n_trg, float* out,
+                                  void* stream) {
+  if (!f0_src || !f0_trg || !out || n_src <= 0 || n_trg <= 0) return HSP_EINVAL;
+  hipLaunchKernelGGL(f0_convert_kernel, dim3(1), dim3(256), 0, HSP_STREAM, f0_src, n_src, f0_trg, n_trg, out);
   return (int)hipGetLastError();
 }
 

@@ -182,3 +182,32 @@ def embedding_sum(ids, tables, n_rows, scale: float, channels: int, out=None):
                                           float(scale), L.fptr(out), out.stride(0), out.stride(1), B, channels, T,
                                           L.stream_ptr()), "hsp_embedding_sum_f32")
     return out
+
+
+def act(x, kind: int):
+    """y = act(x) elementwise (HSP_ACT_*)."""
+    x = _c(x)
+    y = torch.empty_like(x)
+    L.check(L.lib().hsp_act_f32(L.fptr(x), L.fptr(y), x.numel(), kind, L.stream_ptr()), "hsp_act_f32")
+    return y
+
+
+def reflect_pad(x, pad: int):
+    """F.pad(x, (pad, pad), "reflect") on the last axis of [B, L] / [B, 1, L] audio."""
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    assert x2.stride(1) == 1
+    y = torch.empty(x2.shape[0], shp[-1] + 2 * pad, dtype=torch.float32, device=x.device)
+    L.check(L.lib().hsp_reflect_pad_f32(L.fptr(x2), x2.stride(0), L.fptr(y), x2.shape[0], shp[-1], pad, L.stream_ptr()),
+            "hsp_reflect_pad_f32")
+    return y.reshape(*shp[:-1], shp[-1] + 2 * pad)
+
+
+def f0_convert(f0_src, f0_trg):
+    """inference_vc.py:80-81,104-105 for one utterance: -> log(f0' + 1) with the source's voiced frames moved to the
+    target speaker's voiced mean / std."""
+    s, t = _c(f0_src.reshape(-1)), _c(f0_trg.reshape(-1))
+    out = torch.empty_like(s)
+    L.check(L.lib().hsp_f0_convert_f32(L.fptr(s), s.numel(), L.fptr(t), t.numel(), L.fptr(out), L.stream_ptr()),
+            "hsp_f0_convert_f32")
+    return out.reshape(f0_src.shape)

@@ -252,6 +252,7 @@ class Conv1d(_ConvBase):
         super().__init__((cout, cin) if weight_2d else (cout, cin, k), cout, cout if bias else 0, weight_norm)
         self.cin, self.cout, self.k, self.stride, self.padding, self.dilation = cin, cout, k, stride, padding, dilation
         self.rows = rows
+        self.trim_right = 0   # outputs dropped at the end (an even kernel with padding k // 2 yields one too many)
         if rows in (L.ROWS_GATE_WN, L.ROWS_GATE_GLU):
             self.row_map = gated_rows(cout // 2)
         else:
@@ -322,7 +323,7 @@ class Conv1d(_ConvBase):
             r0, r1 = row_range
             assert not gated and r0 % 4 == 0 and 0 <= r0 < r1 <= self.cout
             cout = r1 - r0
-        Lout = (Lin + 2 * self.padding - self.dilation * (self.k - 1) - 1) // self.stride + 1
+        Lout = (Lin + 2 * self.padding - self.dilation * (self.k - 1) - 1) // self.stride + 1 - self.trim_right
         out2 = None
         if split_out is not None:
             split_row, out2, acc2 = split_out
@@ -372,6 +373,17 @@ class Conv1d(_ConvBase):
             return None if rc else (out, out2)
         if direct:
             _launch("hsp_conv1d_direct_f32", L.lib().hsp_conv1d_direct_f32, a, flops, nbytes)
+        elif self.__dict__.get("_pre_norm") is not None and _DEFER is None:
+            # fused input LayerNorm: token-GEMM shapes only (16-B addressable columns).  Any other shape runs the
+            # normalisation as its own launch -- WITHOUT the affine part, which is folded into the packed weights
+            # (W diag(gamma), W beta + b) -- and then the same GEMM: identical arithmetic, one launch more.
+            rc = _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes, soft=True)
+            if rc:
+                from . import functional as Fh
+                xn = Fh.layernorm_mod(x, float(self._pre_norm.eps))
+                a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xn), xn.stride(0), xn.stride(1), xn.stride(2)
+                a.ln_c1 = None
+                _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
         else:
             _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
         return out
@@ -420,6 +432,111 @@ class ConvTranspose1d(_ConvBase):
         nbytes = 4 * (B * Cin * Lin + B * self.cout * Lout * (1 + (res is not None)) + Cin * self.cout * self.k)
         _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
         return out
+
+
+class _SubArena:
+    """arena views of a layer that lives inside another HipLayer (not registered as a sub-module)"""
+
+    def __init__(self, arena, owner, prefix):
+        self.arena, self.owner, self.prefix = arena, owner, prefix
+
+    def view(self, _layer, name):
+        return self.arena.view(self.owner, self.prefix + name)
+
+
+class PolyphaseConv1d(HipLayer):
+    """nn.Conv1d(cin, cout, k, stride = s, padding = 0) on the unit-stride MFMA kernel: taps are grouped by phase
+    p = j mod s, and phase p is a unit-stride conv with ceil((k - p) / s) taps over the strided view x[..., p::s]
+    (hsp_conv1d_args.x_ts = s); the phases accumulate into one output.  Parameters keep nn.Conv1d's names and
+    shapes (``weight`` [cout, cin, k], ``bias``): the feature-encoder layers of wav2vec2 (HF
+    Wav2Vec2LayerNormConvLayer.conv: k 3 / stride 2 and k 2 / stride 2)."""
+
+    def __init__(self, cin, cout, k, stride, bias=True):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        self.weight = nn.Parameter(torch.zeros(cout, cin, k), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False) if bias else None
+        ph = [Conv1d(cin, cout, len(range(p, k, stride)), bias=(bias and p == 0)) for p in range(min(stride, k))]
+        self.__dict__["_phases"] = ph     # not registered: no duplicate state_dict keys
+
+    def hsp_requests(self):
+        return [(f"p{i}.{n}", numel) for i, ph in enumerate(self._phases) for n, numel in ph.hsp_requests()]
+
+    def hsp_fill(self, arena, materialize):
+        for i, ph in enumerate(self._phases):
+            if materialize:
+                ph.weight.data = self.weight.data[:, :, i::self.stride].contiguous()
+                if ph.bias is not None:
+                    ph.bias.data = self.bias.data
+                ph.to(self.weight.device)
+            ph.hsp_fill(_SubArena(arena, self, f"p{i}."), materialize)
+
+    def forward(self, x, **kw):
+        B, Cin, Lin = x.shape
+        Lout = (Lin - self.k) // self.stride + 1
+        out = torch.empty(B, self.cout, Lout, dtype=torch.float32, device=x.device)
+        for i, ph in enumerate(self._phases):
+            xp = x[:, :, i: i + self.stride * (Lout + ph.k - 1): self.stride]     # exactly Lout + K_p - 1 samples
+            ph(xp, out=out, accumulate=i > 0, **(kw if i == len(self._phases) - 1 else {}))
+        return out
+
+
+class GroupedPosConv1d(HipLayer):
+    """HF Wav2Vec2PositionalConvEmbedding.conv + SamePad + GELU + the residual add of the encoder:
+    Conv1d(C, C, k = 128, padding = 64, groups = 16) with weight_norm over dim 2 (one gain per TAP: g [1, 1, k]), last
+    output dropped (even kernel), y = x + gelu(conv(x)).  One group = two MFMA launches on channel-slice views, taps
+    [0, 64) and [64, 128): the conv kernel stages all taps of a channel chunk at once, and 128 taps x 64 rows do not
+    fit its LDS double buffer.  Parameter names: ``weight_g`` / ``weight_v`` (torch <= 2.0 checkpoints;
+    ``parametrizations.weight.original0 / original1`` of newer ones are renamed on load by the owner) and ``bias``."""
+
+    TAPS = 64
+
+    def __init__(self, channels, k, groups):
+        super().__init__()
+        assert k % 2 == 0 and channels % groups == 0 and k % self.TAPS == 0
+        self.channels, self.k, self.groups, self.cg = channels, k, groups, channels // groups
+        self.weight_g = nn.Parameter(torch.ones(1, 1, k), requires_grad=False)
+        self.weight_v = nn.Parameter(torch.zeros(channels, self.cg, k), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(channels), requires_grad=False)
+        subs = []
+        for _ in range(groups):
+            for j0 in range(0, k, self.TAPS):
+                # taps j0 .. j0 + 63 read x[t + j - k / 2]: a conv with padding k / 2 - j0 (negative = a shifted window;
+                # the kernel bounds-checks every read) whose first L outputs are kept: natural length L + 2 pad - 63
+                pad = k // 2 - j0
+                c = Conv1d(self.cg, self.cg, self.TAPS, padding=pad, bias=(j0 == 0))
+                c.trim_right = 2 * pad - (self.TAPS - 1)
+                subs.append(c)
+        self.__dict__["_subs"] = subs
+
+    def hsp_requests(self):
+        return [(f"s{i}.{n}", numel) for i, c in enumerate(self._subs) for n, numel in c.hsp_requests()]
+
+    def hsp_fill(self, arena, materialize):
+        w = None
+        nb = self.k // self.TAPS
+        if materialize:
+            # weight_norm(dim = 2): w[:, :, j] = g[j] * v[:, :, j] / ||v[:, :, j]||_F  == the dim-0 fold of v laid out
+            # [k][C * cg] (a permutation, no arithmetic); folded by the same kernel as every other weight-normed layer
+            vp = self.weight_v.data.permute(2, 0, 1).contiguous().reshape(self.k, -1)
+            w = _fold(vp, self.weight_g.data.reshape(self.k)).reshape(self.k, self.channels, self.cg).permute(1, 2, 0)
+        for i, c in enumerate(self._subs):
+            gi, bi = divmod(i, nb)
+            if materialize:
+                c.weight.data = w[gi * self.cg:(gi + 1) * self.cg, :, bi * self.TAPS:(bi + 1) * self.TAPS].contiguous()
+                if c.bias is not None:
+                    c.bias.data = self.bias.data[gi * self.cg:(gi + 1) * self.cg].contiguous()
+            c.hsp_fill(_SubArena(arena, self, f"s{i}."), materialize)
+
+    def forward(self, x):
+        from . import functional as Fh
+        nb = self.k // self.TAPS
+        conv = torch.empty_like(x)
+        for i, c in enumerate(self._subs):
+            gi, bi = divmod(i, nb)
+            sl = slice(gi * self.cg, (gi + 1) * self.cg)
+            c(x[:, sl], out=conv[:, sl], accumulate=bi > 0)
+        return Fh.axpby(x, Fh.act(conv, L.ACT_GELU_ERF), 1.0, 1.0)
 
 
 class Linear(Conv1d):

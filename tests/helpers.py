@@ -145,6 +145,9 @@ def run_oracle(meta, arrays):
     if kind == "vc_plain":
         return [O.synth_voice_conversion(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"), t("f0"),
                                          meta["noise_scale"], t("noise"))]
+    if kind == "w2v":
+        # synth_sd holds the renamed (weight_g / weight_v) keys the product module uses; the oracle accepts both spellings
+        return [O.wav2vec2_hidden(sd, t("x"), meta["layer"])]
     if kind == "ttv_infer":
         w2v, lf0, _ = O.ttv_infer_one(sd, t("ids"), t("mel"), t("tone"), t("language"), t("dur"))
         return [w2v, lf0]
@@ -206,6 +209,9 @@ def build_module(meta):
     if kind in ("ttv_front", "ttv_gen", "ttv_infer"):
         from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import SynthesizerTrn as Text2W2V
         return Text2W2V(126, 11, 4, 641, 320, 16000, 60, **TTV_MODEL)
+    if kind == "w2v":
+        from megatts2_hierspeechpp_amd.extract_w2v import Wav2vec2
+        return Wav2vec2(layer=meta["layer"])
     if kind in ("speechsr", "speechsr_real"):
         if meta["factor"] == 1.5:    # the 24 kHz model pins x1.5 whatever its config says (speechsr24k/speechsr.py:96)
             from megatts2_hierspeechpp_amd.speechsr24k.speechsr import SynthesizerTrn as SR
@@ -264,6 +270,8 @@ def run_hip(meta, arrays, device):
             xf, g, fl, _ = mod.inf_extract_tc_latent(d("ids"), d("lengths"), d("mel"), d("mel_lengths"), d("tone"),
                                                      d("language"))
             out = [xf, g, fl]
+        elif kind == "w2v":
+            out = [mod(d("x").unsqueeze(1))]
         elif kind == "ttv_infer":
             n = arrays["ids"].shape[1]
             dl = lambda v: torch.tensor(v, dtype=torch.int64, device=device)

@@ -467,8 +467,8 @@ def test_second_output_gemm_matches_two_launches(device):
 
 def test_fused_layernorm_gemm_vs_torch(device):
     """hsp_conv1d_args.ln_c1: y = W LN(x) + b with the LayerNorm folded into the token GEMM (statistics from the
-    staged input tile) against torch's two-pass LayerNorm + Linear; also that shapes outside the token-GEMM path
-    are refused instead of silently dropping the norm."""
+    staged input tile) against torch's two-pass LayerNorm + Linear; also a shape outside the token-GEMM path, where
+    the host layer must fall back to a separate normalisation launch (never silently drop the norm)."""
     from megatts2_hierspeechpp_amd import _lib as L
     from megatts2_hierspeechpp_amd.hip_layers import LinearCT, finalize
     from megatts2_hierspeechpp_amd.ttv_v1.transformer_mega import LayerNorm
@@ -485,8 +485,11 @@ def test_fused_layernorm_gemm_vs_torch(device):
         ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.transpose(1, 2), (cin,), gamma, beta, 1e-5), w, b)
         got = lin(x.to(device), act=L.ACT_RELU).cpu()
         _close(got.numpy(), torch.relu(ref).transpose(1, 2).numpy(), f"ln+gemm {cin}->{cout} N={N}")
-    with pytest.raises(L.HspError):
-        lin(torch.randn(1, 192, 18).to(device))                     # 18 columns: rows are not 16-B addressable
+    # 18 columns: rows are not 16-B addressable, the token GEMM cannot take the fused form -> the host layer runs the
+    # normalisation (without its affine part, which lives in the packed weights) as its own launch; same result
+    x = 2.0 * torch.randn(1, 192, 18, generator=g) - 0.7
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.transpose(1, 2), (192,), gamma, beta, 1e-5), w, b)
+    _close(lin(x.to(device)).cpu().numpy(), ref.transpose(1, 2).numpy(), "ln + gemm, unaligned columns")
 
 
 def test_fused_layernorm_survives_a_large_common_mean(device):
@@ -566,3 +569,59 @@ def test_prompt_mels_and_abi_checks(mel_fn, device):
     lib = L.lib()
     assert lib.hsp_stft_frames_f32(None, None, None, 1, 16000, 1280, 320, 51, 52, None) == L.EINVAL
     assert lib.hsp_power_mel_log_f32(None, 0, 0, None, None, None, None, 1, 641, 80, 50, 0.001, None) == L.EINVAL
+
+
+# ------------------------------------------------------------ inference_vc.py producer
+@pytest.mark.gpu
+def test_f0_conversion_and_reflect_pad_vs_oracle(device):
+    """inference_vc.py:80-81,104-105 (voiced-frame statistics of source and prompt, population std, clip at 0,
+    log(f0 + 1)) and the reflect padding of :85 against their numpy / torch restatements."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from oracle import hsp_oracle as O
+    rng = np.random.default_rng(3)
+    for ns, nt in ((800, 520), (37, 1200)):
+        src = rng.uniform(80, 400, (1, ns)).astype(np.float32)
+        trg = rng.uniform(120, 300, (1, nt)).astype(np.float32)
+        src[0, rng.random(ns) < 0.3] = 0.0
+        trg[0, rng.random(nt) < 0.4] = 0.0
+        want = O.f0_convert(src, trg).numpy()
+        got = Fh.f0_convert(torch.from_numpy(src).to(device), torch.from_numpy(trg).to(device)).cpu().numpy()
+        assert got.shape == want.shape and (got[src == 0] == 0).all()
+        _close(got, want, f"f0 conversion {ns}/{nt}")
+    x = torch.randn(2, 1, 700)
+    want = torch.nn.functional.pad(x, (40, 40), "reflect")
+    got = Fh.reflect_pad(x.to(device), 40).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_vc_tensor_core_runs_and_matches_its_stages(device):
+    """inference_vc.vc end to end on synthetic weights: its int16 output equals the stages run one by one through the
+    oracle-checked pieces (wav2vec2 producer, F0 conversion, prompt mels, voice_conversion_noise_control, int16)."""
+    from megatts2_hierspeechpp_amd import functional as Fh, inference_vc as IV, synth
+    from megatts2_hierspeechpp_amd.Mels_preprocess import MelSpectrogramFixed
+    from megatts2_hierspeechpp_amd.inference_plm import peak_int16
+    from oracle.hsp_oracle import default_config
+    models = IV.VcModels(default_config())
+    models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 2)) for k, v in models.state_dict().items()})
+    models.finalize(device)
+    mel_fn = MelSpectrogramFixed(sample_rate=16000, n_fft=1280, win_length=1280, hop_length=320, f_min=0, f_max=8000,
+                                 n_mels=80, window_fn=torch.hann_window).finalize(device)
+    src = torch.from_numpy(_prompt_audio(1, 12000, 5)).to(device)
+    src = IV.pad_source(src)                                   # -> 12800 samples = 40 w2v frames
+    trg = torch.from_numpy(_prompt_audio(1, 9000, 6)).to(device)
+    rng = np.random.default_rng(8)
+    f0s = torch.from_numpy(np.where(rng.random((1, 160)) < 0.3, 0, rng.uniform(90, 300, (1, 160))).astype(np.float32)).to(device)
+    f0t = torch.from_numpy(np.where(rng.random((1, 112)) < 0.3, 0, rng.uniform(150, 350, (1, 112))).astype(np.float32)).to(device)
+    noise = torch.randn(1, 192, 40, device=device)
+    wav, audio = IV.vc(models, mel_fn, src, f0s, trg, f0t, noise_scale_vc=0.333, denoise_ratio=0.0, noise=noise,
+                       return_float=True)
+    assert wav.dtype == torch.int16 and wav.shape == (40 * 320,) and bool(torch.isfinite(audio).all())
+    w2v = models.w2v(Fh.reflect_pad(src, 40))
+    assert w2v.shape == (1, 1024, 40)
+    mel2 = mel_fn(torch.cat([trg, trg], 0))
+    ref = models.voc.voice_conversion_noise_control(w2v, torch.tensor([40], device=device), mel2,
+                                                    torch.tensor([mel2.shape[2]] * 2, device=device),
+                                                    Fh.f0_convert(f0s, f0t), noise_scale=0.333, denoise_ratio=0.0, noise=noise)
+    assert torch.equal(audio, ref)
+    assert torch.equal(wav, peak_int16(ref.reshape(1, -1), torch.tensor([ref.shape[-1]], device=device)).reshape(-1))

@@ -299,18 +299,74 @@ def ttv_cases():
          [audio, t(wav.astype(np.float32))], [oaudio, t(owav.astype(np.float32))])
 
 
+# ------------------------------------------------------------------- wav2vec2 producer (N2)
+def w2v_cases():
+    """extract_w2v.Wav2vec2 (reference extract_w2v.py:16-46) = hidden_states[7] of HF Wav2Vec2ForPreTraining with the
+    MMS-300M topology.  The reference class loads facebook/mms-300m from a local path in its constructor (no
+    checkpoint offline), so the fixture is generated from the imported third-party classes themselves, with the
+    synthetic weight recipe and the reference's call (``wav2vec2(x.squeeze(1), output_hidden_states=True)``,
+    ``hidden_states[layer].permute(0, 2, 1)``).  8 encoder layers are enough for hidden_states[7] (the stream entering
+    layer 7); the real model's layers 8..23 never touch it."""
+    import transformers
+    W = 7
+    cfg = transformers.Wav2Vec2Config(
+        hidden_size=1024, num_hidden_layers=8, num_attention_heads=16, intermediate_size=4096, conv_dim=(512,) * 7,
+        conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_bias=True, feat_extract_norm="layer",
+        do_stable_layer_norm=True, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16, layer_norm_eps=1e-5,
+        hidden_act="gelu", feat_extract_activation="gelu", hidden_dropout=0.0, attention_dropout=0.0,
+        activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0)
+    hf = transformers.Wav2Vec2ForPreTraining(cfg).eval()
+
+    class Wrap(nn.Module):           # the attribute layout of extract_w2v.Wav2vec2: self.wav2vec2 = ForPreTraining
+        def __init__(self):
+            super().__init__()
+            self.wav2vec2 = hf
+
+        def forward(self, x):
+            out = self.wav2vec2(x.squeeze(1), output_hidden_states=True)
+            return out.hidden_states[7].permute((0, 2, 1))
+
+    net = Wrap().eval()
+    from megatts2_hierspeechpp_amd.extract_w2v import Wav2vec2
+    # torch >= 2.1 spells the weight-norm pair parametrizations.weight.original0 / original1; the recipe is keyed by the
+    # classic names (weight_g / weight_v), which is also what the product module and older checkpoints use
+    ren = lambda k: k.replace("conv.parametrizations.weight.original0", "conv.weight_g") \
+                     .replace("conv.parametrizations.weight.original1", "conv.weight_v")
+    shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = {k: torch.from_numpy(synth.synth_tensor(ren(k), s_, W)) for k, s_ in shapes}
+    net.load_state_dict(sd, strict=True)
+    sd = {ren(k): v for k, v in sd.items()}
+    mine = set(Wav2vec2(7).state_dict().keys())
+    used = [(ren(k), s_) for k, s_ in shapes if ren(k) in mine]
+    assert len(used) == len(mine), (len(used), len(mine), sorted(mine - {k for k, _ in used})[:5])
+    for case, B, n in [("w2v_hidden7_t25", 1, 8000 + 80), ("w2v_hidden7_b2_t50", 2, 16000 + 80)]:
+        tt = np.arange(n) / 16000.0
+        x = np.stack([(0.3 * np.sin(2 * np.pi * (170 + 60 * b) * tt) * (1 + 0.5 * np.sin(2 * np.pi * 3 * tt))
+                       + 0.05 * np.random.default_rng(90 + b).standard_normal(n)).astype(np.float32) for b in range(B)])
+        ref = net(t(x).unsqueeze(1))
+        orc = O.wav2vec2_hidden(sd, t(x), 7)
+        save(case, dict(kind="w2v", prefix="", seed=W, shapes=used, layer=7, renamed_parametrizations=True), dict(x=x),
+             ref, orc)
+
+
 # ----------------------------------------------------------------------------- cases
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv"],
-                    help="vocoder: hierspeechpp/attentions/speechsr cases; ttv: ttv_v1 front-end + PLM cases")
+    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv", "w2v"],
+                    help="vocoder: hierspeechpp/attentions/speechsr cases; ttv: ttv_v1 front-end + PLM cases; "
+                         "w2v: the wav2vec2 producer of inference_vc.py")
     args = ap.parse_args()
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
     install_stubs()
     sys.path.insert(0, args.ref)
     os.makedirs(OUT, exist_ok=True)
+    if args.group in ("all", "w2v"):
+        with torch.no_grad():
+            w2v_cases()
+    if args.group == "w2v":
+        return
     if args.group in ("all", "ttv"):
         with torch.no_grad():
             ttv_cases()
