@@ -625,3 +625,68 @@ def test_vc_tensor_core_runs_and_matches_its_stages(device):
                                                     Fh.f0_convert(f0s, f0t), noise_scale=0.333, denoise_ratio=0.0, noise=noise)
     assert torch.equal(audio, ref)
     assert torch.equal(wav, peak_int16(ref.reshape(1, -1), torch.tensor([ref.shape[-1]], device=device)).reshape(-1))
+
+
+# ------------------------------------------------------------ BASELINE.json configs[2] and configs[3] at full size
+@pytest.mark.gpu
+def test_tts_b16_full_size_properties(device):
+    """configs[2]: 16 utterances x 40 phones x 10 frames -> 4 s each through the whole text -> wav chain (front-end,
+    200-step PLM loop, w2v / pitch decoder, vocoder, int16).  The oracle needs tens of minutes here, so: shape, range
+    and determinism of the int16 batch; every row peak-normalised on its own (its largest sample is 32767 x 0.999
+    truncated); and rows are independent up to the first greedy PLM code that a near-tie flips -- an utterance run
+    alone gives the same waveform over the audio that precedes that code."""
+    from megatts2_hierspeechpp_amd import inference_plm as IP, synth
+    from oracle.hsp_oracle import default_config
+    models = IP.TtsModels(default_config(), H.TTV_MODEL)
+    models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0)) for k, v in models.state_dict().items()})
+    models.finalize(device)
+    r = np.random.default_rng(3)
+    B, N, Tm = 16, 40, 150
+    ids = torch.from_numpy(r.integers(12, 113, (B, N))).to(device)
+    tone = torch.from_numpy(r.integers(0, 11, (B, N))).to(device)
+    lang = torch.where(ids < 74, 1, 2)
+    tl = torch.full((B,), N, dtype=torch.int64, device=device)
+    mel = torch.from_numpy(synth.synth_inputs(B, Tm, seed=5)["mel"]).to(device)
+    ml = torch.full((B,), Tm, dtype=torch.int64, device=device)
+    dur = torch.full((B, N), 10.0, device=device)
+    T2 = N * 10 // 2
+    noise = torch.from_numpy(r.standard_normal((B, 192, T2)).astype(np.float32)).to(device)
+    run = lambda s: IP.tts(models, ids[s], tl[s], tone[s], lang[s], mel[s], ml[s], torch.cat([mel[s], mel[s]]),
+                           torch.cat([ml[s], ml[s]]), dur=dur[s], noise=noise[s], return_float=True)
+    wav, audio = run(slice(0, B))
+    wav2, _ = run(slice(0, B))
+    assert wav.shape == (B, 320 * T2) and wav.dtype == torch.int16 and torch.equal(wav, wav2)
+    assert bool(torch.isfinite(audio).all()) and float(audio.abs().max()) <= 1.0
+    peaks = wav.int().abs().amax(dim=1)
+    assert int(peaks.min()) >= 32732 and int(peaks.max()) <= 32734, peaks     # 32767 * 0.999 = 32734.2, truncated
+    for b in (0, 11):
+        _, a1 = run(slice(b, b + 1))
+        diff = (a1[0].reshape(-1) - audio[b].reshape(-1)).abs()
+        bad = (diff > 1e-4).nonzero()
+        first = int(bad[0]) if bad.numel() else diff.numel()
+        assert first >= 320 * 100, f"row {b}: batch and alone differ from sample {first} on"   # >= 2 s in common
+
+
+@pytest.mark.gpu
+def test_vocoder_sr48_b32_full_size_properties(device):
+    """configs[3]: vocoder 32 x 4 s -> SpeechSR48.  Output [32, 1, 192000] finite, inside tanh's range and
+    deterministic; SpeechSR is a per-utterance conv chain, so every row equals the row run alone; and one full-size
+    utterance agrees with the oracle's SpeechSR on the same 16 kHz input."""
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    from megatts2_hierspeechpp_amd.speechsr48k.speechsr import SynthesizerTrn as SpeechSR
+    from oracle import hsp_oracle as O
+    sr = SpeechSR(128, 30, "0", [3, 7, 11], [[1, 3, 5]] * 3, [3], 32, [3])
+    sd = {k: torch.from_numpy(synth.synth_tensor("sr." + k, tuple(v.shape), 0)) for k, v in sr.state_dict().items()}
+    sr.load_state_dict(sd)
+    finalize(sr, device)
+    B, n = 32, 64000
+    tt = np.arange(n) / 16000.0
+    x = np.stack([0.3 * np.sin(2 * np.pi * (110 + 13 * b) * tt) + 0.1 * np.sin(2 * np.pi * (1500 + 40 * b) * tt) for b in range(B)])
+    x = torch.from_numpy(x.astype(np.float32)).unsqueeze(1).to(device)
+    y, y2 = sr(x), sr(x)
+    assert y.shape == (B, 1, 3 * n) and bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0 and torch.equal(y, y2)
+    for b in (0, 17, 31):
+        assert float((sr(x[b:b + 1])[0] - y[b]).abs().max()) <= 2e-5
+    want = O.speechsr(sd, x[5:6].cpu(), 3, "dec")
+    _close(y[5:6].cpu().numpy(), want.numpy(), "SpeechSR48 at 4 s vs oracle")

@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r01_traffic.json
-(KB summed per kernel class; bench.py reads conv1d_mfma_bytes_per_step for `roofline.traffic`).
-    python tools/pmc_summarize.py gpurun_out profiles/r01_traffic.json"""
+"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r02_traffic.json.
+bench.py quotes `roofline.traffic` from that file ONLY when the library hash, the workload size and the launch mix
+recorded here equal the run's own.
+
+    python tools/pmc_summarize.py gpurun_out profiles/r02_traffic.json
+
+FETCH_SIZE on gfx950 under-reports wide coalesced reads (exactly 1/2 for 16-B-per-lane streams, MI355X_MICROARCH.md);
+three figures are given for every kernel class: raw (as counted), x2 (the guide's literal correction) and calibrated
+(x the factor that makes act1d_seg_kernel's FETCH equal its independently known read bytes: B C L 4 per launch)."""
 import csv
 import glob
+import hashlib
 import json
-import re
+import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-CLASSES = ["conv1d_mfma_kernel", "tokgemm_kernel", "act1d_seg_kernel", "act1d_kernel", "mha_mfma_kernel", "mha_kernel", "layernorm",
-           "conv1d_direct_kernel"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLASSES = ["conv1d_mfma_kernel", "gemm2_kernel", "tokgemm_kernel", "act1d_seg_kernel", "act1d_kernel", "mha_mfma_kernel",
+           "mha_kernel", "layernorm", "conv1d_direct_kernel"]
+B, T = 32, 200
+STEPS = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
 
 
 def cls(name):
@@ -31,42 +41,42 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         k[f"{counter}_KB"] += float(row["Counter_Value"])
         if counter == "FETCH_SIZE":
             k["launches"] += 1
-steps = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
+
+# algorithmic bytes of the stand-alone activation launches of one vocoder step (one read, one write per element): the
+# 91 Activation1d of the Generator + 37 of the SourceNetwork at their (C, L) -- bench.py's ACT_HOOK sums the same figure
+act = out["act1d_seg_kernel"]
+stage = [(512, 800), (256, 4000), (128, 16000), (64, 32000), (32, 64000)]
+act_elems = sum(18 * c * l for c, l in stage) + 32 * 64000           # generator: 18 per stage + activation_post
+act_elems += 18 * (256 * 400 + 128 * 800) + 128 * 800                # source network stages (256, 400), (128, 800) + post
+act_read_bytes = 4.0 * B * act_elems * STEPS
+fetch_factor = act_read_bytes / (act["FETCH_SIZE_KB"] * 1024)
+write_check = (4.0 * B * act_elems * STEPS) / (act["WRITE_SIZE_KB"] * 1024)
 
 
-def _cal(counter, sub):
-    """average counter value (bytes) per conv launch of the calibration case"""
-    files = glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True)
-    vals = [float(r["Counter_Value"]) * 1024 for r in csv.DictReader(open(sorted(files)[-1]))
-            if r["Counter_Name"] == counter and "conv1d_mfma_kernel" in r["Kernel_Name"]]
-    return sum(vals) / len(vals)
+def three(k):
+    f, w = k["FETCH_SIZE_KB"] * 1024 / STEPS, k["WRITE_SIZE_KB"] * 1024 / STEPS
+    return {"raw": f + w, "x2": 2 * f + w, "calibrated": fetch_factor * f + w, "fetch_raw": f, "write_raw": w}
 
 
-# calibration case of tools/pmc_traffic.sh: conv 128 -> 128, k = 3, L = 16000, B = 8, no activation, no residual,
-# one row tile: reads = input once + 2 halo columns per 128-column tile + weights, writes = output once
-CAL_READ = 8 * 128 * 16000 * 4 * (130 / 128) + 3 * 128 * 128 * 4
-CAL_WRITE = 8 * 128 * 16000 * 4
-fetch_factor = CAL_READ / _cal("FETCH_SIZE", "traffic_cal_f")
-write_factor = CAL_WRITE / _cal("WRITE_SIZE", "traffic_cal_w")
+with open(os.path.join(ROOT, "megatts2_hierspeechpp_amd", "libhsp.so"), "rb") as fh:
+    sha = hashlib.sha256(fh.read()).hexdigest()[:16]
 conv = out["conv1d_mfma_kernel"]
 res = {
-    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-graph "
-            "--no-roofline` (= 2 executed steps); values are KB summed over all launches of a kernel class, as the "
-            "counters report them.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE under-reports wide coalesced reads "
-            "(exactly 1/2 for 16-B/lane streaming reads) and other access shapes must be calibrated in the kernel's own "
-            "pattern.  Calibration case (same kernel, known bytes: conv 128->128 k3, L=16000, B=8, no activation): the "
-            "factors below = expected / reported; conv1d_mfma_bytes_per_step applies them (FETCH x fetch_factor + "
-            "WRITE x write_factor)",
-    "fetch_factor": fetch_factor, "write_factor": write_factor,
-    "steps_in_run": steps, "batch_per_gpu": 32, "frames": 200, "kernels": out,
-    "conv1d_mfma_bytes_per_step": (conv["FETCH_SIZE_KB"] * fetch_factor + conv["WRITE_SIZE_KB"] * write_factor) * 1024 / steps,
-    "conv1d_mfma_bytes_per_step_uncorrected": (conv["FETCH_SIZE_KB"] + conv["WRITE_SIZE_KB"]) * 1024 / steps,
-    "conv1d_mfma_launches_per_step": conv["launches"] / steps,
+    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 1 --warmup 0 --no-graph "
+            "--no-roofline` (2 executed steps); per kernel class KB as counted.  FETCH calibrated on the step's own "
+            "act1d_seg_kernel launches (known bytes: one fp32 read per element); write_check = known / counted write "
+            "bytes of the same launches (the guide: WRITE_SIZE is exact for 16-B stores).",
+    "lib_sha16": sha, "batch_per_gpu": B, "frames": T, "steps_in_run": STEPS,
+    "fetch_factor": fetch_factor, "write_check": write_check, "kernels": out,
+    "conv1d_mfma_launches_per_step": conv["launches"] // STEPS,
+    "act1d_launches_per_step": act["launches"] // STEPS,
+    "conv1d_mfma_bytes_per_step": three(conv),
+    "act1d_seg_bytes_per_step": three(act),
 }
-act = out.get("act1d_seg_kernel")
-if act:
-    # 16-B/lane streaming global_load: FETCH_SIZE reports exactly 1/2 (MI355X_MICROARCH.md, HBM); stores read exactly
-    res["act1d_seg_bytes_per_step"] = (2.0 * act["FETCH_SIZE_KB"] + act["WRITE_SIZE_KB"]) * 1024 / steps
-    res["act1d_seg_launches_per_step"] = act["launches"] / steps
+for name in ("gemm2_kernel", "tokgemm_kernel"):
+    if name in out:
+        res[name + "_bytes_per_step"] = three(out[name])
 json.dump(res, open(dst, "w"), indent=1)
-print({k: res[k] for k in ("fetch_factor", "write_factor", "conv1d_mfma_bytes_per_step", "conv1d_mfma_launches_per_step")})
+print({k: res[k] for k in ("lib_sha16", "fetch_factor", "write_check", "conv1d_mfma_launches_per_step", "act1d_launches_per_step")})
+print("conv1d_mfma GB/step", {k: round(v / 1e9, 2) for k, v in res["conv1d_mfma_bytes_per_step"].items()})
+print("act1d_seg GB/step", {k: round(v / 1e9, 2) for k, v in res["act1d_seg_bytes_per_step"].items()})
