@@ -42,9 +42,11 @@ int validate(const hsp_conv1d_args& a) {
 int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   const bool gated = a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU;
   const bool act = a.prologue == HSP_PRO_ACT1D;
-  // "short": even 128 x 128 tiles would leave CUs idle; prefer small tiles with deep chunks so
-  // that every CU gets work and each tile sees few global-load round trips
-  const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B < 256;
+  // "short": 128 x 128 tiles would leave at least half of the 256 CUs idle; prefer 64 x 64 tiles with deep
+  // chunks so that more CUs get work.  A lone 64 x 64 tile takes half as long as a lone 128 x 128 one (measured:
+  // 36 us against 67 us at C = 128, k = 7) for a quarter of the work, so the small shape wins up to 64 big tiles,
+  // ties up to 128 and loses 2x beyond (tools/conv_sweep.py, profiles/r02_tile_threshold.txt).
+  const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B <= 128;
   if ((short_seq || a.ln_c1 || a.split_row) && !HSP_DBG(a, 128)) {
     // 1x1 GEMMs over a few thousand token columns: the latency-oriented kernel (hsp_tokgemm.hip)
     const int e = hsp_tokgemm_try(a, s, plan_out);
@@ -53,19 +55,19 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused input LayerNorm / second output: token-GEMM path only
   int epi = select_epilogue(a);
   if (act && epi != HSP_EPI_INIT) epi = HSP_EPI_GEN;  // the activation shapes carry INIT and GEN only
+#ifdef HSP_TUNING
+  // force a tile shape (results stay right)
+  if (!gated && a.debug & 256) return hsp_conv_tile_M128(a, epi, act, s, plan_out);
+  if (!gated && a.debug & 1024) return hsp_conv_tile_M64(a, epi, act, s, plan_out);
+  if (!gated && a.debug & 4096) return hsp_conv_tile_S64(a, epi, act, s, plan_out);
+  if (!gated && a.debug & 8192) return hsp_conv_tile_M64P(a, epi, act, s, plan_out);
+#endif
   if (short_seq) {
     if (gated) return hsp_conv_tile_S64G(a, epi, act, s, plan_out);
     if (a.M > 32) return hsp_conv_tile_S64(a, epi, act, s, plan_out);
     return hsp_conv_tile_S32(a, epi, act, s, plan_out);
   }
   if (gated) return hsp_conv_tile_M128(a, epi, act, s, plan_out);
-#ifdef HSP_TUNING
-  // force a tile shape (results stay right)
-  if (a.debug & 256) return hsp_conv_tile_M128(a, epi, act, s, plan_out);
-  if (a.debug & 1024) return hsp_conv_tile_M64(a, epi, act, s, plan_out);
-  if (a.debug & 4096) return hsp_conv_tile_S64(a, epi, act, s, plan_out);
-  if (a.debug & 8192) return hsp_conv_tile_M64P(a, epi, act, s, plan_out);
-#endif
   // M > 128: 128 x 128 tiles at two workgroups per CU.  (A 256 x 128 one-per-CU shape existed in round 1; in
   // units of one 128 x 128 tile's MFMA time a CU spends 2 ceil(n256 / 256) against ceil(n128 / 256) <= that, and
   // it lost or tied on every layer of the path, so it is gone.)

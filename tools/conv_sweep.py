@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Several conv shapes x tuning words in ONE process (kernel decomposition; needs the tuning build:
    HSP_LIB=megatts2_hierspeechpp_amd/libhsp_tune.so python tools/conv_sweep.py [--shapes ...] [--debug 0 1 2 16 17]
-A shape is C:L:K[:dil[:res[:B]]].  Prints us per launch and algorithmic TFLOP/s (debug != 0: results are wrong,
+A shape is C:L:K[:dil[:res[:B[:Cout]]]].  Prints us per launch and algorithmic TFLOP/s (debug != 0: results are wrong,
 the time is what is being measured)."""
 import argparse
 import os
@@ -26,19 +26,24 @@ for shp in a.shapes:
     dil = f[3] if len(f) > 3 else 1
     res_on = f[4] if len(f) > 4 else 1
     B = f[5] if len(f) > 5 else 32
-    conv = hip_layers.Conv1d(C_, C_, K, dilation=dil, padding=(K - 1) * dil // 2)
+    Co = f[6] if len(f) > 6 else C_
+    conv = hip_layers.Conv1d(C_, Co, K, dilation=dil, padding=(K - 1) * dil // 2)
     conv.weight.data.normal_(0, 0.05)
     conv.bias.data.normal_(0, 0.1)
     hip_layers.finalize(conv, dev)
     x = torch.randn(B, C_, L, device=dev)
-    res = torch.randn(B, C_, L, device=dev) if res_on else None
-    out = torch.empty(B, C_, L, device=dev)
-    fl = 2.0 * B * C_ * C_ * K * L
+    res = torch.randn(B, Co, L, device=dev) if res_on else None
+    out = torch.empty(B, Co, L, device=dev)
+    fl = 2.0 * B * C_ * Co * K * L
     row = []
     for dbg in a.debug:
         hip_layers.DEBUG_FLAGS = dbg
-        for _ in range(3):
-            conv(x, res=res, out=out)
+        try:
+            for _ in range(3):
+                conv(x, res=res, out=out)
+        except Exception:
+            row.append(f"dbg{dbg}: n/a")
+            continue
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -48,4 +53,4 @@ for shp in a.shapes:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.reps
         row.append(f"dbg{dbg}: {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF")
-    print(f"C {C_:4d} L {L:6d} K {K:2d} d {dil} res {res_on} B {B:2d} | " + " | ".join(row), flush=True)
+    print(f"C {C_:4d}>{Co:4d} L {L:6d} K {K:2d} d {dil} res {res_on} B {B:2d} | " + " | ".join(row), flush=True)
