@@ -61,7 +61,7 @@ enum {
 
 namespace hspconv {
 
-template <int WM, int WN, int TM, int TN, int NPW_, int MINW_>
+template <int WM, int WN, int TM, int TN, int NPW_, int MINW_, int XSLACK_ = 64>
 struct Cfg {
   static constexpr int NCW = WM * WN;              // consumer waves (4, or 8 = two per SIMD)
   static constexpr int kWM = WM, kWN = WN, kTM = TM, kTN = TN;
@@ -71,13 +71,17 @@ struct Cfg {
   static constexpr int NPT = NPW_ * 64;            // producer threads
   static constexpr int THREADS = 64 * (WM * WN + NPW_);
   static constexpr int MINW = MINW_;               // waves per SIMD the register allocation must allow
+  // LDS row pitch of the input window, a compile-time constant so that the consumer loop can reach the next
+  // channel pair through ds_read immediates: BN columns + halo (K-1)*dil + 3 (the 16-B window DMA starts at the
+  // aligned position below p0) must fit; a multiple of 64 (DMA instructions never straddle rows)
+  static constexpr int XWP = BN + XSLACK_;
 };
 
 struct LdsPlan {
   int kc, lkc;  // chunk depth (power of two) and its log2
   int rpw;      // channel rows per producer wave and chunk
   int xw;       // activated window width  = BN + (K-1)*dil
-  int xwp;      // its LDS row pitch (multiple of 64: DMA instructions never straddle rows)
+  int xwp;      // its LDS row pitch (Cfg::XWP)
   int xrw;      // raw window width        = xw + 10        (ACT1D)
   int xrwp;     // raw row pitch in the producer scratch (multiple of 64)
   int a2w;      // 2x-rate window width    = 2*xw + 10      (ACT1D)
@@ -92,7 +96,7 @@ __host__ __device__ inline LdsPlan make_plan(int K, int dil, int prologue, int l
   p.kc = 1 << lkc;
   p.rpw = (p.kc + C::NPW - 1) / C::NPW;
   p.xw = C::BN + (K - 1) * dil;
-  p.xwp = (p.xw + 3 + 63) & ~63;  // +3: the 16-B window DMA starts at the aligned position below p0
+  p.xwp = C::XWP;  // valid only while xw + 3 <= XWP (pick_lkc checks)
   p.xrw = p.xw + 10;
   p.xrwp = (p.xrw + 63) & ~63;
   p.a2w = 2 * p.xw + 10;
@@ -134,6 +138,16 @@ __device__ __forceinline__ void ds_read_frags(float (&f)[N], unsigned addr) {
   if constexpr (I < N) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[I]) : "v"(addr), "n"(I * 128));
     ds_read_frags<N, I + 1>(f, addr);
+  }
+}
+
+// the same from a compile-time byte offset: f[i] = lds[addr + OFF + i * 128 B]
+template <int N, int OFF, int I = 0>
+__device__ __forceinline__ void ds_read_frags_at(float (&f)[N], unsigned addr) {
+  if constexpr (I < N) {
+    static_assert(OFF + I * 128 < 65536, "ds_read immediate offsets are 16 bits");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[I]) : "v"(addr), "n"(OFF + I * 128));
+    ds_read_frags_at<N, OFF, I + 1>(f, addr);
   }
 }
 
@@ -600,60 +614,75 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
 
   const int wlane = half * BM + wm * (TM * 32) + l32;
   const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? (p0 & 3) : 0);
-  const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4
-  const int a_step = KC * BM;          // next tap, same channel pair
+  const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4, so a tap has an even number of channel pairs
 
   lds_barrier();  // chunk 0 staged
-  for (int c = 0; c < nchunks; ++c) {
-    const int cb = c & 1;
-    const float* const ws = lds + cb * P.ws_sz + wlane;
-    const float* const xs = lds + P.xa_off + cb * P.xa_sz + xlane;
-    // k-steps ordered channel-pair outer, tap inner; the (tap, pair) -> LDS offset walk is
-    // scalar.  Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of
-    // step s+1 are issued right after the wait that retires the reads of step s and BEFORE
-    // the 8..16 MFMAs of step s, so an LDS round trip never sits between two MFMA groups
-    // (left to itself hipcc sinks the prefetch under the MFMAs and waits on it at once).
-    int offA = 0, offB = 0, j = 0, kk = 0;
-    auto advance = [&]() __attribute__((always_inline)) {
-      const bool wrap = (j + 1 == a.K);
-      kk += wrap ? 1 : 0;
-      j = wrap ? 0 : j + 1;
-      offA = wrap ? 2 * kk * BM : offA + a_step;
-      offB = wrap ? 2 * kk * P.xwp : offB + a.dil;
-    };
-    const unsigned aA = lds_addr(ws), aB = lds_addr(xs);  // per-lane LDS byte addresses
-    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto read_set = [&](float (&fa)[TM], float (&fb)[TN], unsigned va, unsigned vb) __attribute__((always_inline)) {
-      ds_read_frags<TM>(fa, va);
-      ds_read_frags<TN>(fb, vb);
-    };
-    auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
+  // k-steps ordered tap outer, channel pair inner.  The weight slab is [tap][channel][row], so the A side is
+  // one linear walk (1 KB per step for BM = 128); the B side moves one pair (2 window rows) per step and one tap
+  // (dil columns) per KC / 2 steps.  A trip is two steps of the same tap: the second step's addresses are the
+  // first's plus compile-time immediates (Cfg::XWP is a constant of the shape), so a trip costs two VALU adds and six scalar instructions, no branch.  With fp32
+  // MFMAs sharing the VALU datapath that matters: tools/micro/mfma_loop_bench.hip loses 5 % of the matrix pipe to
+  // two VALU adds per step and 11 % more to a branchy tap wrap (what this loop looked like in round 1).
+  // Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of step s+1 are issued right
+  // after the wait that retires the reads of step s and BEFORE the MFMAs of step s, so an LDS round trip never
+  // sits between two MFMA groups (left to itself hipcc sinks the prefetch under the MFMAs and waits at once).
+  {
+    constexpr int kStepA = 2 * BM * 4;     // bytes: next channel pair in the weight slab
+    constexpr int rowB = 2 * C::XWP * 4;   // bytes: next channel pair in the window
+    const int spanB = (KC >> 1) * rowB;    // all pairs of one tap
+    const int tapB = 4 * a.dil;
+    for (int c = 0; c < nchunks; ++c) {
+      const int cb = c & 1;
+      const unsigned aA = lds_addr(lds + cb * P.ws_sz + wlane);           // per-lane LDS byte addresses
+      const unsigned aB = lds_addr(lds + P.xa_off + cb * P.xa_sz + xlane);
+      int offA = 0, pairB = 0, tapoff = 0;  // scalar byte offsets of the current trip
+      auto advance = [&]() __attribute__((always_inline)) {
+        int t;
+        asm volatile(
+            "s_add_i32 %[oa], %[oa], %[sa]\n\t"
+            "s_add_i32 %[pb], %[pb], %[sb]\n\t"
+            "s_cmp_eq_u32 %[pb], %[span]\n\t"
+            "s_cselect_b32 %[pb], 0, %[pb]\n\t"
+            "s_cselect_b32 %[t], %[tap], 0\n\t"
+            "s_add_i32 %[to], %[to], %[t]"
+            : [oa] "+s"(offA), [pb] "+s"(pairB), [to] "+s"(tapoff), [t] "=&s"(t)
+            : [sa] "n"(2 * kStepA), [sb] "n"(2 * rowB), [span] "s"(spanB), [tap] "s"(tapB)
+            : "scc");
+      };
+      float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+      auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
-    };
-    read_set(fa0, fb0, aA, aB);
-    for (int s = HSP_DBG(a, 2) ? nsteps : 0; s < nsteps; s += 2) {
-      advance();  // step s+1 (always valid: nsteps is even)
-      unsigned va = aA + 4u * (unsigned)offA, vb = aB + 4u * (unsigned)offB;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
-      __builtin_amdgcn_sched_barrier(0);
-      read_set(fa1, fb1, va, vb);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
-      mma_set(fa0, fb0);
-      advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
-      const bool more = s + 2 < nsteps;
-      va = aA + 4u * (unsigned)(more ? offA : 0);
-      vb = aB + 4u * (unsigned)(more ? offB : 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
-      __builtin_amdgcn_sched_barrier(0);
-      read_set(fa0, fb0, va, vb);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_set(fa1, fb1);
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
+      };
+      unsigned va = aA, vb = aB;
+      ds_read_frags<TM>(fa0, va);
+      ds_read_frags<TN>(fb0, vb);
+      for (int s = HSP_DBG(a, 2) ? nsteps : 0; s < nsteps; s += 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
+        __builtin_amdgcn_sched_barrier(0);
+        // step s+1: same tap, next pair
+        ds_read_frags_at<TM, kStepA>(fa1, va);
+        ds_read_frags_at<TN, rowB>(fb1, vb);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
+        mma_set(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);  // or the MFMAs sink below the next wait, which then follows its reads at once
+        advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
+        const bool more = s + 2 < nsteps;
+        va = aA + (unsigned)(more ? offA : 0);
+        vb = aB + (unsigned)(more ? pairB + tapoff : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
+        __builtin_amdgcn_sched_barrier(0);
+        ds_read_frags<TM>(fa0, va);
+        ds_read_frags<TN>(fb0, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();
     }
-    lds_barrier();
   }
 
   // ---- epilogue.  static_for keeps every accumulator index a compile-time constant: a runtime
@@ -863,6 +892,7 @@ constexpr int kLdsTarget = 80 * 1024;  // two workgroups per CU when possible
 template <class C>
 int pick_lkc(const hsp_conv1d_args& a, int lds_limit) {
   const bool act = a.prologue == HSP_PRO_ACT1D;
+  if (C::BN + (a.K - 1) * a.dil + 3 > C::XWP) return -1;  // halo beyond this shape's window pitch
   int cin_p2 = 2;
   while ((1 << cin_p2) < a.Cin && cin_p2 < 6) ++cin_p2;  // no point staging past Cin
   for (int lkc = cin_p2; lkc >= 2; --lkc) {
@@ -932,12 +962,13 @@ using M32P = Cfg<1, 4, 1, 4, 4, 4>;    //  32 x 512, likewise
 using S64 = Cfg<2, 2, 1, 1, 4, 2>;     //  64 x 64   short sequences: many small, deep-chunk tiles
 using S64G = Cfg<1, 4, 2, 1, 4, 2>;    //  64 x 128  short sequences, gated rows (needs TM even)
 using S32 = Cfg<1, 4, 1, 1, 4, 2>;     //  32 x 128
+using S64W = Cfg<2, 2, 1, 1, 4, 2, 128>;   //  64 x 64 with a 192-float window pitch: halos of 62 ... 125 columns
 
 }  // namespace hspconv
 
 // One function per tile shape (hsp_conv1d_tile.hip, compiled once per shape): launches the instantiation
 // for (epi, act) or returns HSP_EINVAL when the shape does not carry that combination.
-#define HSP_TILE_LIST(X) X(M128) X(M64) X(M32) X(M64P) X(M32P) X(S64) X(S64G) X(S32)
+#define HSP_TILE_LIST(X) X(M128) X(M64) X(M32) X(M64P) X(M32P) X(S64) X(S64G) X(S32) X(S64W)
 #define HSP_TILE_DECL(name) \
   int hsp_conv_tile_##name(const hsp_conv1d_args& a, int epi, bool act, hipStream_t s, int32_t* plan_out);
 HSP_TILE_LIST(HSP_TILE_DECL)

@@ -1,11 +1,11 @@
 // One tile shape of the fused conv kernel (hsp_conv1d_mfma_kernel.h) per translation unit: the Makefile
-// compiles this file once per shape with -DHSP_TILE=<shape>, so the nine shapes build in parallel.
+// compiles this file once per shape with -DHSP_TILE=<shape>, so the shapes build in parallel.
 // Each shape carries only the (epilogue kind, activation prologue) combinations the dispatcher
 // (hsp_conv1d_mfma.hip) routes to it.
 #include "hsp_conv1d_mfma_kernel.h"
 
 #ifndef HSP_TILE
-#error "compile with -DHSP_TILE=<M128|M64|M32|M64P|M32P|S64|S64G|S32>"
+#error "compile with -DHSP_TILE=<M128|M64|M32|M64P|M32P|S64|S64G|S32|S64W>"
 #endif
 
 namespace {
@@ -19,7 +19,7 @@ template <int EPI, bool ACT>
 constexpr bool supported() {
   if (same<T, S64G>) return EPI == HSP_EPI_GATE && !ACT;
   if (same<T, M64> || same<T, M32>) return ACT && (EPI == HSP_EPI_INIT || EPI == HSP_EPI_GEN);  // activation shapes
-  if (ACT) return (same<T, M128> || same<T, S64> || same<T, S32>) && (EPI == HSP_EPI_INIT || EPI == HSP_EPI_GEN);
+  if (ACT) return (same<T, M128> || same<T, S64> || same<T, S64W> || same<T, S32>) && (EPI == HSP_EPI_INIT || EPI == HSP_EPI_GEN);
   if (EPI == HSP_EPI_GATE) return same<T, M128>;
   if (EPI == HSP_EPI_SHUF) return true;  // every plain shape (ConvTranspose of a single short utterance: S64 / S32)
   return true;  // INIT / VEC / GEN on every plain shape
