@@ -127,6 +127,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// tuning build: bit 2048 drops the chunk barriers (wrong results; what do they cost?  nothing measurable)
+#define HSP_BARRIER(a) do { if (!HSP_DBG(a, 2048)) lds_barrier(); } while (0)
+
 // 32-bit LDS byte address of a pointer into the workgroup's dynamic shared memory
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
         PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0, 0, p0a, pw, lane);
         wait_vm0();
         if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
-        lds_barrier();
+        HSP_BARRIER(a);
         for (int c = 0; c < nchunks; ++c) {
           const int nb = (c + 1) & 1;
           if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
             wait_vm0();
             if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
           }
-          lds_barrier();
+          HSP_BARRIER(a);
         }
         return;
       }
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
       wait_vm0();
       if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
-      lds_barrier();
+      HSP_BARRIER(a);
       for (int c = 0; c < nchunks; ++c) {
         const int nb = (c + 1) & 1;
         if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
           wait_vm0();
           if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
         }
-        lds_barrier();
+        HSP_BARRIER(a);
       }
     } else {
       float* const scr = lds + P.scr_off + pw * P.scr_sz;   // raw[2][rpw][xrwp], a2[a2w]
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       PR::act_rows(pa, P, scr, a2, Xa0, 0, p0, pw, lane);
       if (nchunks > 1) PR::dma_raw(pa, P, scr + rsz, xb, KC, p0, pw, lane);
       wait_vm0();
-      lds_barrier();
+      HSP_BARRIER(a);
       for (int c = 0; c < nchunks; ++c) {
         const int nb = (c + 1) & 1;
         if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
           PR::act_rows(pa, P, scr + nb * rsz, a2, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0, pw, lane);
           wait_vm0();
         }
-        lds_barrier();
+        HSP_BARRIER(a);
       }
     }
     return;
@@ -616,11 +619,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
   const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? (p0 & 3) : 0);
   const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4, so a tap has an even number of channel pairs
 
-  lds_barrier();  // chunk 0 staged
+  HSP_BARRIER(a);  // chunk 0 staged
   // k-steps ordered tap outer, channel pair inner.  The weight slab is [tap][channel][row], so the A side is
   // one linear walk (1 KB per step for BM = 128); the B side moves one pair (2 window rows) per step and one tap
   // (dil columns) per KC / 2 steps.  A trip is two steps of the same tap: the second step's addresses are the
-  // first's plus compile-time immediates (Cfg::XWP is a constant of the shape), so a trip costs two VALU adds and six scalar instructions, no branch.  With fp32
+  // first's plus compile-time immediates (Cfg::XWP is a constant of the shape), so a trip costs two VALU adds and
+  // six scalar instructions, no branch.  With fp32
   // MFMAs sharing the VALU datapath that matters: tools/micro/mfma_loop_bench.hip loses 5 % of the matrix pipe to
   // two VALU adds per step and 11 % more to a branchy tap wrap (what this loop looked like in round 1).
   // Fragment reads are hand-placed (inline asm + explicit lgkmcnt): the reads of step s+1 are issued right
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
         mma_set(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      lds_barrier();
+      HSP_BARRIER(a);
     }
   }
 

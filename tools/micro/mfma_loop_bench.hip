@@ -3,6 +3,8 @@
 //   V0 MFMAs only | V1 + 4 ds_read_b32 (prefetch distance one step) + s_waitcnt | V2 + 2 VALU address adds
 //   V3 + scalar bookkeeping and a branch (the tap wrap of the real loop) | V4 = V1 with a 3 x 2 tile (6 MFMAs, 5 reads)
 //   V5 = V1 without the wait (wrong data: is it the wait?) | V6 = V1 with the reads between the MFMAs
+//   V10 / V11 / V12 = the conv kernel's round-2 loop (trip of two steps, immediates, scalar walk) with 2 / 1 / 0
+//   VALU address adds per trip | V13 / V14 = V10 with the adds between the MFMAs of a group
 //   V8 = the same 16 B per lane as 2 x ds_read_b64 | V9 = as 1 x ds_read_b128
 // at 1 and 2 consumer waves per SIMD, 256 workgroups (one per CU).
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_loop_bench.hip -o /tmp/mfma_loop_bench && /tmp/mfma_loop_bench
@@ -33,10 +35,111 @@ __global__ __launch_bounds__(512) void loop(float* out, int iters, int wrap, int
   unsigned pa = lane * 4, pb = 8192 + lane * 4;
   float a0 = 1.0f, a1 = 1.0f, a2 = 1.0f, b0 = 1.0f, b1 = 1.0f, na0, na1, na2, nb0, nb1;
   int tap = 0, ci = 0;
-  if (V >= 1) {
+  if (V >= 1 && V < 10) {
     rd(a0, pa, 0); rd80(a1, pa); rd(b0, pb, 0); rd80(b1, pb);
     if (V == 4) rd100(a2, pa);
   }
+  if (V == 13 || V == 14) {
+    // V10 with the two VALU adds issued between the MFMAs of the first group (V13: after the first, V14: after the
+    // third) instead of after the group: the adds then cost their own cycles, not a drain of the matrix pipe
+    int offA = 0, pairB = 0, tapoff = 0;
+    unsigned va = pa, vb = pb;
+    rd(a0, va, 0); rd80(a1, va); rd(b0, vb, 0); rd80(b1, vb);
+    for (int it = 0; it < iters; it += 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("ds_read_b32 %0, %1 offset:0x400" : "=v"(na0) : "v"(va) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:0x480" : "=v"(na1) : "v"(va) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:0x600" : "=v"(nb0) : "v"(vb) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:0x680" : "=v"(nb1) : "v"(vb) : "memory");
+      int t;
+      asm volatile(
+          "s_add_i32 %[oa], %[oa], 0x800\n\t"
+          "s_add_i32 %[pb], %[pb], 0xc00\n\t"
+          "s_cmp_eq_u32 %[pb], %[span]\n\t"
+          "s_cselect_b32 %[pb], 0, %[pb]\n\t"
+          "s_cselect_b32 %[t], %[tap], 0\n\t"
+          "s_add_i32 %[to], %[to], %[t]"
+          : [oa] "+s"(offA), [pb] "+s"(pairB), [to] "+s"(tapoff), [t] "=&s"(t)
+          : [span] "s"(stride_a * 24), [tap] "s"(wrap * 4)
+          : "scc");
+      const bool more = it + 2 < iters;
+      const unsigned sa = (unsigned)((more ? offA : 0) & 4095), sb = (unsigned)((more ? pairB + tapoff : 0) & 4095);
+      __builtin_amdgcn_sched_barrier(0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
+      if (V == 13) {
+        __builtin_amdgcn_sched_barrier(0);
+        va = pa + sa; vb = pb + sb;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
+      if (V == 14) {
+        __builtin_amdgcn_sched_barrier(0);
+        va = pa + sa; vb = pb + sb;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na0), "+v"(na1), "+v"(nb0), "+v"(nb1)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rd(a0, va, 0); rd80(a1, va); rd(b0, vb, 0); rd80(b1, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(na0, nb0, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(na0, nb1, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(na1, nb0, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(na1, nb1, c11, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
+  if (V >= 10) {
+    // the conv kernel's loop after round 2: a trip of two steps, second step through immediates, a branch-free
+    // scalar walk per trip and NV = V - 10 ... VALU address adds per trip (2 = the kernel, 1, 0)
+    int offA = 0, pairB = 0, tapoff = 0;
+    unsigned va = pa, vb = pb;
+    rd(a0, va, 0); rd80(a1, va); rd(b0, vb, 0); rd80(b1, vb);
+    for (int it = 0; it < iters; it += 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("ds_read_b32 %0, %1 offset:0x400" : "=v"(na0) : "v"(va) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:0x480" : "=v"(na1) : "v"(va) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:0x600" : "=v"(nb0) : "v"(vb) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:0x680" : "=v"(nb1) : "v"(vb) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      int t;
+      asm volatile(
+          "s_add_i32 %[oa], %[oa], 0x800\n\t"
+          "s_add_i32 %[pb], %[pb], 0xc00\n\t"
+          "s_cmp_eq_u32 %[pb], %[span]\n\t"
+          "s_cselect_b32 %[pb], 0, %[pb]\n\t"
+          "s_cselect_b32 %[t], %[tap], 0\n\t"
+          "s_add_i32 %[to], %[to], %[t]"
+          : [oa] "+s"(offA), [pb] "+s"(pairB), [to] "+s"(tapoff), [t] "=&s"(t)
+          : [span] "s"(stride_a * 24), [tap] "s"(wrap * 4)
+          : "scc");
+      const bool more = it + 2 < iters;
+      if (V == 10) {
+        va = pa + (unsigned)((more ? offA : 0) & 4095);
+        vb = pb + (unsigned)((more ? pairB + tapoff : 0) & 4095);
+      } else if (V == 11) {
+        vb = pb + (unsigned)((more ? pairB + tapoff : 0) & 4095);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na0), "+v"(na1), "+v"(nb0), "+v"(nb1)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rd(a0, va, 0); rd80(a1, va); rd(b0, vb, 0); rd80(b1, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(na0, nb0, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(na0, nb1, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(na1, nb0, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(na1, nb1, c11, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
   if (V == 8 || V == 9) {
     unsigned wa = lane * 16, wb = 8192 + lane * 16;
     f32x2 x0 = {1.0f, 1.0f}, x1 = x0, y0 = x0, y1 = x0;
@@ -138,6 +241,11 @@ int main() {
   hipFuncSetAttribute((const void*)loop<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipFuncSetAttribute((const void*)loop<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipFuncSetAttribute((const void*)loop<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)loop<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)loop<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)loop<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)loop<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)loop<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   for (int w : {1, 2}) {
     const int iters = 800000 / w;
     run<0>(w, iters, d);
@@ -150,6 +258,11 @@ int main() {
     run<6>(w, iters, d);
     run<8>(w, iters, d);
     run<9>(w, iters, d);
+    run<10>(w, iters, d);
+    run<11>(w, iters, d);
+    run<12>(w, iters, d);
+    run<13>(w, iters, d);
+    run<14>(w, iters, d);
   }
   return 0;
 }

@@ -34,7 +34,7 @@ out = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"{src}/traffic_{counter}/**/*counter_collection.csv", recursive=True)
     assert files, f"no counter csv for {counter}"
-    for row in csv.DictReader(open(sorted(files)[-1])):
+    for row in csv.DictReader(open(max(files, key=os.path.getmtime))):  # newest pass (gpurun_out keeps older ones)
         if row["Counter_Name"] != counter:
             continue
         k = out.setdefault(cls(row["Kernel_Name"]), {"launches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})

@@ -7,7 +7,10 @@
 # known independently of the kernel being judged.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+# the same launch mix as bench.py's own per-launch pass (one stream, the 50 Hz part as one batch group)
+export HSP_AMP_STREAMS=0 HSP_FRONT_SPLITS=1
 for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $R/gpurun_out/traffic_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-roofline --no-extra > $R/gpurun_out/traffic_$c.log 2>&1
 done
 ls $R/gpurun_out | grep traffic

@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export HSP_AMP_STREAMS=0 HSP_FRONT_SPLITS=1
+rm -rf $R/gpurun_out/prof_final
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python3 $R/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extra > $R/gpurun_out/prof_final.log 2>&1
 grep '^{' $R/gpurun_out/prof_final.log | tail -1 > $R/gpurun_out/prof_final_bench.json
 find $R/gpurun_out/prof_final -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/prof_final_kernel_stats.csv
