@@ -179,6 +179,43 @@ int hsp_reflect_pad_f32(const float* x, int64_t x_bs, float* y, int32_t B, int32
  * elsewhere.  One utterance per call (the statistics are per utterance): f0_src [n_src], f0_trg [n_trg]. */
 int hsp_f0_convert_f32(const float* f0_src, int32_t n_src, const float* f0_trg, int32_t n_trg, float* out, void* stream);
 
+/* ----------------------------------------------- prompt denoiser (MP-SENet) */
+/* The parts of denoiser/ that are neither convolutions nor GEMMs (those run on hsp_conv1d_mfma_f32 /
+ * hsp_conv1d_direct_f32 / hsp_mha_f32 / hsp_layernorm_mod_f32).  One utterance per call, as the reference
+ * (denoiser/infer.py:3-10 takes a 1-D prompt). */
+/* out[0] = sum_i x[i]^2 (double accumulation): the norm factor sqrt(len / sum) of denoiser/infer.py:4. */
+int hsp_sum_sq_f32(const float* x, int64_t n, float* out, void* stream);
+/* mag[f][t] = |z|^compress, pha[f][t] = angle(z) for z = spec[f][t] + i spec[n_freqs + f][t] (row pitch s_ld):
+ * mag_pha_stft of denoiser/infer.py:12-24 after the DFT product; the imaginary part of the DC and Nyquist rows is
+ * taken as +0, as a real FFT returns it.  mag, pha contiguous [n_freqs, T]. */
+int hsp_mag_pha_f32(const float* spec, int64_t s_ld, float* mag, float* pha, int32_t n_freqs, int32_t T, float compress,
+                    void* stream);
+/* In place: nn.InstanceNorm2d(C, affine=True) then nn.PReLU(C) over the N contiguous values of each of the C
+ * channel planes at x + c * x_cs (biased variance, double accumulation as torch's CPU path):
+ * denoiser/generator.py:22-23,40-41,47-48,65-66,83-84. */
+int hsp_instnorm_prelu_f32(float* x, int64_t x_cs, int32_t C, int64_t N, const float* gamma, const float* beta,
+                           const float* slope, float eps, void* stream);
+/* y = SiLU(BatchNorm1d_eval(depthwise Conv1d(x))) over contiguous [B, C, N]; w [C, K] (K odd, padding K / 2),
+ * batch-norm as y = x alpha + (bias - mean alpha), alpha = weight / sqrt(var + eps): denoiser/conformer.py:34-37. */
+int hsp_dwconv_bn_silu_f32(const float* x, const float* w, const float* bias, const float* bn_weight,
+                           const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps, float* y,
+                           int32_t B, int32_t C, int32_t N, int32_t K, void* stream);
+/* out[t][f] = mag[t][f] * beta * sigmoid(slope[f] * m[t][f]): LearnableSigmoid_2d (denoiser/utils.py:44-53) and the
+ * mask product of generator.py:140; all [T, F] contiguous. */
+int hsp_lsigmoid_mul_f32(const float* m, const float* slope, float beta, const float* mag, float* out, int32_t T,
+                         int32_t F, void* stream);
+/* out[i] = atan2(y[i], x[i]): PhaseDecoder.forward (denoiser/generator.py:96). */
+int hsp_atan2_f32(const float* y, const float* x, float* out, int64_t n, void* stream);
+/* re[f][t] = mag[f][t]^power cos(pha[f][t]), im likewise with sin (row pitches re_ld / im_ld): denoised_com of
+ * generator.py:142-143 (power 1) and the decompression of mag_pha_istft (infer.py:26-29, power 1 / compress). */
+int hsp_polar_f32(const float* mag, const float* pha, float power, float* re, int64_t re_ld, float* im, int64_t im_ld,
+                  int32_t F, int32_t T, void* stream);
+/* torch.istft(center=True) after the inverse DFT: out[n] = scale * sum_t frames[k][t] w[k] / sum_t w[k]^2 with
+ * k = n + n_fft / 2 - t hop in [0, n_fft), n < hop (T - 1); frames [n_fft, f_ld] (denoiser/infer.py:30-31 and the
+ * division by the norm factor at :9). */
+int hsp_istft_ola_f32(const float* frames, int64_t f_ld, const float* window, float* out, int32_t n_fft, int32_t hop,
+                      int32_t T, float scale, void* stream);
+
 /* ------------------------------------------------------- anti-aliased activation */
 /* y = DownSample2x(SnakeBeta(UpSample2x(x))): alias_free_torch/act.py:23-28,
  * resample.py:25-33,47-49, filter.py:86-95, activations.py:107-119.  x, y contiguous

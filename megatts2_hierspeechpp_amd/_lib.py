@@ -94,6 +94,15 @@ SIGNATURES = {
     "hsp_act_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp]),
     "hsp_reflect_pad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_f0_convert_f32": (C.c_int, [_fp, C.c_int32, _fp, C.c_int32, _fp, _fp]),
+    "hsp_sum_sq_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+    "hsp_mag_pha_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int32, C.c_int32, C.c_float, _fp]),
+    "hsp_instnorm_prelu_f32": (C.c_int, [_fp, C.c_int64, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_float, _fp]),
+    "hsp_dwconv_bn_silu_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, _fp]),
+    "hsp_lsigmoid_mul_f32": (C.c_int, [_fp, _fp, C.c_float, _fp, _fp, C.c_int32, C.c_int32, _fp]),
+    "hsp_atan2_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp]),
+    "hsp_polar_f32": (C.c_int, [_fp, _fp, C.c_float, _fp, C.c_int64, _fp, C.c_int64, C.c_int32, C.c_int32, _fp]),
+    "hsp_istft_ola_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp]),
     "hsp_maxpool1d_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_vq_nearest_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, _fp]),

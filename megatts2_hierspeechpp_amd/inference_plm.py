@@ -2,8 +2,9 @@
 extraction and wav writing, :156-190, and the model bundle of ``model_load`` :203-263).
 
 Out of scope here (host plumbing, not the hot path): text cleaning / phonemisation
-(``get_text``), audio file IO and resampling, the mel spectrogram transform and the optional
-denoiser -- callers hand over phone ids and mels, exactly the tensors ``tts()`` feeds its models."""
+(``get_text``), audio file IO and resampling -- callers hand over phone ids and the prompt waveform (or its mels),
+exactly the tensors ``tts()`` feeds its models.  The prompt mel transform is ``Mels_preprocess.MelSpectrogramFixed``,
+the optional prompt denoiser ``denoiser.generator.MPNet`` + ``denoiser.infer.denoise`` (:142-147)."""
 from __future__ import annotations
 
 import math
@@ -58,18 +59,27 @@ def peak_int16(audio, lengths=None, gain: float = 0.999):
     return out
 
 
-def prompt_mels(mel_fn, audio):
-    """The two prompt mels of inference_plm.py:130-150 (denoise_ratio = 0 branch): ``src_mel_ttv`` from the prompt
-    zero-padded to the next multiple of 1600 samples (always at least one sample of padding, :131-134), and
-    ``src_mel`` [2, 80, T] from the un-padded prompt stacked twice (:144,150).  ``audio`` [1, n] fp32 on the GPU;
-    ``mel_fn`` a finalized Mels_preprocess.MelSpectrogramFixed."""
+def prompt_mels(mel_fn, audio, denoiser=None, hps_denoiser=None):
+    """The two prompt mels of inference_plm.py:130-150: ``src_mel_ttv`` from the prompt zero-padded to the next
+    multiple of 1600 samples (always at least one sample of padding, :131-134), and ``src_mel`` [2, 80, T] from the
+    un-padded prompt stacked with itself (denoise_ratio = 0, :142-143) or with its denoised version cut to the same
+    length (``denoiser`` = a finalized denoiser.generator.MPNet, ``hps_denoiser`` its config: :144-150; the denoiser
+    sees the PADDED prompt, as in the reference).  ``audio`` [1, n] fp32 on the GPU; ``mel_fn`` a finalized
+    Mels_preprocess.MelSpectrogramFixed."""
     n = audio.shape[-1]
     padded = torch.zeros(audio.shape[0], (n // 1600 + 1) * 1600, dtype=audio.dtype, device=audio.device)
     padded[:, :n].copy_(audio)
     src_mel_ttv = mel_fn(padded)
-    src_mel = mel_fn(audio)
-    src_mel = src_mel.repeat(2, 1, 1) if src_mel.shape[0] == 1 else torch.cat([src_mel, src_mel], 0)
-    return src_mel_ttv, src_mel
+    if denoiser is None:
+        src_mel = mel_fn(audio)
+        src_mel = src_mel.repeat(2, 1, 1) if src_mel.shape[0] == 1 else torch.cat([src_mel, src_mel], 0)
+        return src_mel_ttv, src_mel
+    if audio.shape[0] != 1:
+        raise L.HspError("the prompt denoiser takes one prompt per call, as the reference")
+    from .denoiser.infer import denoise
+    den = denoise(padded[0], denoiser, hps_denoiser)                  # [1, len(padded)] (1600 is a multiple of the hop)
+    both = torch.cat([padded, den[:, :padded.shape[-1]]], 0)[:, :n]   # :147,150 (copies, no arithmetic)
+    return src_mel_ttv, mel_fn(both.contiguous())
 
 
 def write_wav(path, sample_rate: int, pcm):
@@ -128,12 +138,16 @@ def tts(models: TtsModels, text, text_length, tone, language, src_mel_ttv, src_m
 
 @torch.no_grad()
 def tts_from_prompt(models: TtsModels, mel_fn, text, tone, language, prompt_audio, output_path=None,
-                    noise_scale_vc: float = 0.333, output_sr: int = 16000, dur=None, noise=None):
-    """inference_plm.py:tts :126-201 from the prompt WAVEFORM on (denoise_ratio = 0 branch): prompt mels
-    (:130-150, `prompt_mels`), text -> w2v / f0 -> waveform (`tts`), optional 16-bit WAV (:195-200).
+                    noise_scale_vc: float = 0.333, output_sr: int = 16000, dur=None, noise=None,
+                    denoise_ratio: float = 0.0, denoiser=None, hps_denoiser=None):
+    """inference_plm.py:tts :126-201 from the prompt WAVEFORM on: prompt mels (:130-150, `prompt_mels`; with
+    ``denoise_ratio`` > 0 the second prompt mel comes from the denoised prompt and the style vectors are mixed by
+    voice_conversion_noise_control), text -> w2v / f0 -> waveform (`tts`), optional 16-bit WAV (:195-200).
     text / tone / language int64 [1, N] on the GPU; prompt_audio fp32 [1, n] at 16 kHz on the GPU;
     ``mel_fn`` a finalized Mels_preprocess.MelSpectrogramFixed.  Returns int16 [n_out]."""
-    src_mel_ttv, src_mel = prompt_mels(mel_fn, prompt_audio)
+    if denoise_ratio != 0 and denoiser is None:
+        raise L.HspError("denoise_ratio > 0 needs the denoiser model (denoiser.generator.MPNet), as inference_plm.py:144-147")
+    src_mel_ttv, src_mel = prompt_mels(mel_fn, prompt_audio, denoiser if denoise_ratio != 0 else None, hps_denoiser)
     dev = prompt_audio.device
     B = text.shape[0]
     assert B == 1 and prompt_audio.shape[0] == 1, "the reference harness synthesises one utterance per call"
@@ -141,7 +155,7 @@ def tts_from_prompt(models: TtsModels, mel_fn, text, tone, language, prompt_audi
     ttv_len = torch.full((B,), src_mel_ttv.shape[2], dtype=torch.int64, device=dev)
     src_length2 = torch.full((2 * B,), src_mel.shape[2], dtype=torch.int64, device=dev)
     wav = tts(models, text, text_length, tone, language, src_mel_ttv, ttv_len, src_mel, src_length2,
-              noise_scale_vc=noise_scale_vc, denoise_ratio=0.0, output_sr=output_sr, dur=dur, noise=noise)[0]
+              noise_scale_vc=noise_scale_vc, denoise_ratio=float(denoise_ratio), output_sr=output_sr, dur=dur, noise=noise)[0]
     if output_path is not None:
         write_wav(output_path, output_sr if output_sr in (24000, 48000) else 16000, wav)
     return wav

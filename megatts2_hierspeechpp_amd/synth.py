@@ -11,14 +11,18 @@ multi-GPU run) can regenerate any tensor independently of iteration order.
   the flow parity would be vacuous)
 * nn.LSTM matrices ``N(0,1)/sqrt(fan_in)``, nn.LayerNorm gains ``1 + 0.1·N``
 * resample filters: the closed-form 12-tap kaiser-sinc
+* denoiser: PReLU slopes ``0.25 + 0.1·N``, BatchNorm statistics with positive variance, ``in_proj`` like a Linear
 """
 from __future__ import annotations
 
 import math
+import re
 import zlib
 from typing import Dict, Iterable, Tuple
 
 import numpy as np
+
+_PRELU_KEY = re.compile(r"(dense_conv_\d|dense_block\.\d+|phase_conv)\.2\.weight$|mask_conv\.3\.weight$")
 
 
 def kaiser_sinc_filter12() -> np.ndarray:
@@ -56,6 +60,20 @@ def synth_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
     if leaf == "gamma":
         return 1.0 + 0.1 * n()
     if leaf == "beta":
+        return 0.1 * n()
+    if leaf == "weight" and len(shape) == 1 and _PRELU_KEY.search(key):   # nn.PReLU slope (MP-SENet denoiser)
+        return 0.25 + 0.1 * n()
+    if leaf == "slope":                                # LearnableSigmoid_2d
+        return 1.0 + 0.3 * n()
+    if leaf == "running_var":                          # nn.BatchNorm1d statistics
+        return 0.5 + np.abs(n())
+    if leaf == "running_mean":
+        return 0.1 * n()
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, np.int64)
+    if leaf == "in_proj_weight":                       # nn.MultiheadAttention
+        return n() / math.sqrt(shape[1])
+    if leaf == "in_proj_bias":
         return 0.1 * n()
     if leaf in ("emb_rel_k", "emb_rel_v"):
         return n() * (shape[-1] ** -0.5)

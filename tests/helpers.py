@@ -25,6 +25,12 @@ TTV_MODEL = dict(inter_channels=256, hidden_channels=256, filter_channels=1024, 
                  resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], use_spectral_norm=False)
 
 
+# denoiser/config.json of the reference (hyper-parameters, not code)
+import types  # noqa: E402
+DENOISER_H = types.SimpleNamespace(dense_channel=64, compress_factor=0.3, num_tsconformers=4, beta=2.0,
+                                   sampling_rate=16000, n_fft=400, hop_size=100, win_size=400)
+
+
 def fixture_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
 
@@ -151,6 +157,13 @@ def run_oracle(meta, arrays):
     if kind == "ttv_infer":
         w2v, lf0, _ = O.ttv_infer_one(sd, t("ids"), t("mel"), t("tone"), t("language"), t("dur"))
         return [w2v, lf0]
+    if kind == "mp_conformer":
+        return [O.mp_conformer_block(sd, name, t("x"))]
+    if kind == "mp_dense_encoder":
+        return [O.mp_dense_encoder(sd, name, t("x"))]
+    if kind == "denoise":
+        audio, amp, _ = O.denoise(sd, name, t("wav"), spectrogram=(t("amp_in"), t("pha_in")))
+        return [audio, amp]
     raise KeyError(kind)
 
 
@@ -212,6 +225,12 @@ def build_module(meta):
     if kind == "w2v":
         from megatts2_hierspeechpp_amd.extract_w2v import Wav2vec2
         return Wav2vec2(layer=meta["layer"])
+    if kind in ("mp_conformer", "mp_dense_encoder", "denoise"):
+        from megatts2_hierspeechpp_amd.denoiser import conformer, generator
+        h = DENOISER_H
+        if kind == "mp_conformer":
+            return conformer.ConformerBlock(dim=64, n_head=4, ccm_kernel_size=31)
+        return generator.DenseEncoder(h, in_channel=2) if kind == "mp_dense_encoder" else generator.MPNet(h)
     if kind in ("speechsr", "speechsr_real"):
         if meta["factor"] == 1.5:    # the 24 kHz model pins x1.5 whatever its config says (speechsr24k/speechsr.py:96)
             from megatts2_hierspeechpp_amd.speechsr24k.speechsr import SynthesizerTrn as SR
@@ -272,6 +291,25 @@ def run_hip(meta, arrays, device):
             out = [xf, g, fl]
         elif kind == "w2v":
             out = [mod(d("x").unsqueeze(1))]
+        elif kind == "mp_conformer":
+            # the reference holds [A, N, C]; the product module is channel-major [A, C, N]
+            out = [mod(d("x").transpose(1, 2).contiguous()).transpose(1, 2)]
+        elif kind == "mp_dense_encoder":
+            out = [mod(d("x"))]
+        elif kind == "denoise":
+            # The network and the inverse STFT against the reference, on the spectrogram the REFERENCE run saw (stored
+            # in the fixture): the first and last frame of a centred, reflect-padded STFT are even-symmetric, their
+            # spectrum is real up to rounding, and the phase of a negative real number with noise for an imaginary part
+            # is +pi or -pi by the accident of the FFT's summation order -- a 2 pi jump in an input FEATURE of the
+            # network that no other DFT implementation (not even torch.stft on another CPU) reproduces.  The product
+            # STFT itself is compared on the continuous quantities in test_denoiser_stft; the whole product call in
+            # test_denoise_end_to_end.
+            from megatts2_hierspeechpp_amd.denoiser.infer import mag_pha_istft
+            w = torch.from_numpy(arrays["wav"])
+            norm = torch.sqrt(len(w) / torch.sum(w ** 2.0))
+            amp_in, pha_in = d("amp_in"), d("pha_in")
+            amp_g, pha_g, _ = mod(amp_in, pha_in)
+            out = [mag_pha_istft(amp_g, pha_g, 400, 100, 400, 0.3, scale=1.0 / float(norm)), amp_g]
         elif kind == "ttv_infer":
             n = arrays["ids"].shape[1]
             dl = lambda v: torch.tensor(v, dtype=torch.int64, device=device)

@@ -429,6 +429,51 @@ def test_tts_from_prompt_waveform(mel_fn, device, tmp_path):
     assert rate == 16000 and np.array_equal(back, wav.cpu().numpy())
 
 
+def test_tts_from_prompt_with_denoiser(mel_fn, device):
+    """The denoise_ratio > 0 branch of the harness (inference_plm.py:144-150,172-173): the second prompt mel comes from
+    the denoised, padded prompt cut back to the prompt's length, and the vocoder mixes the two style vectors.  Checked
+    against the same steps done by hand, and for the effect of the ratio."""
+    from megatts2_hierspeechpp_amd import _lib as L, inference_plm as IP, synth
+    from megatts2_hierspeechpp_amd.denoiser.generator import MPNet
+    from megatts2_hierspeechpp_amd.denoiser.infer import denoise
+    from oracle.hsp_oracle import default_config
+    models = IP.TtsModels(default_config(), H.TTV_MODEL)
+    models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 7)) for k, v in models.state_dict().items()})
+    models.finalize(device)
+    den = MPNet(H.DENOISER_H)
+    den.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 7)) for k, v in den.state_dict().items()})
+    den.finalize(device)
+    r = np.random.default_rng(6)
+    N = 6
+    ids = torch.from_numpy(r.integers(12, 113, (1, N))).to(device)
+    tone = torch.from_numpy(r.integers(0, 11, (1, N))).to(device)
+    lang = torch.where(ids < 74, 1, 2)
+    prompt = torch.from_numpy(_prompt_audio(1, 9000, 2)).to(device)
+    dur = torch.full((1, N), 4.0, device=device)
+    noise = torch.from_numpy(r.standard_normal((1, 192, N * 2)).astype(np.float32)).to(device)
+    kw = dict(dur=dur, noise=noise, denoiser=den, hps_denoiser=H.DENOISER_H)
+    w08 = IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, denoise_ratio=0.8, **kw)
+    w00 = IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, denoise_ratio=0.0, **kw)
+    assert w08.dtype == torch.int16 and w08.shape == w00.shape == (N * 2 * 320,)
+    assert not torch.equal(w08, w00)                                          # the style mix moved the output
+    assert torch.equal(w08, IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, denoise_ratio=0.8, **kw))
+    # by hand: pad to the next multiple of 1600, denoise the padded prompt, cut both to the prompt's length
+    n = prompt.shape[1]
+    padded = torch.zeros(1, (n // 1600 + 1) * 1600, device=device)
+    padded[:, :n] = prompt
+    d = denoise(padded[0], den, H.DENOISER_H)
+    assert d.shape == padded.shape
+    mel2 = mel_fn(torch.cat([prompt, d[:, :n]], 0).contiguous())
+    mel_ttv, mel2_p = IP.prompt_mels(mel_fn, prompt, den, H.DENOISER_H)
+    assert torch.equal(mel2, mel2_p) and not torch.equal(mel2[0], mel2[1])
+    ref = IP.tts(models, ids, torch.tensor([N], device=device), tone, lang, mel_ttv,
+                 torch.tensor([mel_ttv.shape[2]], device=device), mel2, torch.tensor([mel2.shape[2]] * 2, device=device),
+                 denoise_ratio=0.8, dur=dur, noise=noise)[0]
+    assert torch.equal(w08, ref)
+    with pytest.raises(L.HspError):
+        IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, denoise_ratio=0.8, dur=dur, noise=noise)
+
+
 def test_second_output_gemm_matches_two_launches(device):
     """hsp_conv1d_args.split_row: one token-GEMM launch for the two row halves of a WN res_skip layer
     (modules.py:166-174) == the two separate launches, bit for bit; shapes without a fused kernel are refused
@@ -690,3 +735,57 @@ def test_vocoder_sr48_b32_full_size_properties(device):
         assert float((sr(x[b:b + 1])[0] - y[b]).abs().max()) <= 2e-5
     want = O.speechsr(sd, x[5:6].cpu(), 3, "dec")
     _close(y[5:6].cpu().numpy(), want.numpy(), "SpeechSR48 at 4 s vs oracle")
+
+
+# ------------------------------------------------------------------ prompt denoiser
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8000, 14400, 5137])
+def test_denoiser_stft(device, n):
+    """mag_pha_stft against torch.stft (what denoiser/infer.py:12-24 calls) on the continuous quantities: the compressed
+    magnitude and the complex spectrum mag * (cos, sin).  The phase itself is compared where it is well defined
+    (|imag| above the rounding noise, or a positive real part)."""
+    from megatts2_hierspeechpp_amd.denoiser.infer import mag_pha_stft
+    g = torch.Generator().manual_seed(n)
+    wav = (0.2 * torch.randn(n, generator=g) + 0.3 * torch.sin(torch.arange(n) * 0.07)).unsqueeze(0)
+    spec = torch.stft(wav, 400, hop_length=100, win_length=400, window=torch.hann_window(400), center=True,
+                      pad_mode="reflect", normalized=False, return_complex=True)
+    mag_r, pha_r = torch.abs(spec) ** 0.3, torch.angle(spec)
+    mag, pha, com = mag_pha_stft(wav.to(device), 400, 100, 400, 0.3)
+    assert mag.shape == mag_r.shape == pha.shape
+    _close(mag.cpu().numpy(), mag_r.numpy(), "mag")
+    com_r = torch.stack((mag_r * torch.cos(pha_r), mag_r * torch.sin(pha_r)), -1)
+    _close(com.cpu().numpy(), com_r.numpy(), "com")
+    solid = (spec.imag.abs() > 1e-4 * spec.abs().max()) | (spec.real > 0)
+    d = (pha.cpu() - pha_r).abs()[solid]
+    assert float(d.max()) < 2e-3, float(d.max())
+    # DC and Nyquist rows carry an exact +0 imaginary part, as a real FFT returns it: phase 0 or +pi, never -pi
+    assert float(pha[0, [0, 200]].min()) >= 0.0
+
+
+@pytest.mark.gpu
+def test_denoise_end_to_end(device):
+    """The whole product call denoise(wav, model, hps) against the oracle.  The phase branches of the two edge frames
+    are not reproducible across DFT implementations (helpers.run_hip, kind "denoise"; oracle.denoise), so the oracle is
+    given the spectrogram the product STFT produced -- itself held to torch.stft by test_denoiser_stft -- and
+    everything after it (network, decompression, inverse STFT, normalisation) must agree to the usual bar."""
+    from oracle import hsp_oracle as O
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.denoiser.infer import denoise, mag_pha_stft
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    meta, arrays = H.load_fixture("denoise_l8000")
+    mod = H.build_module(meta)
+    mod.load_state_dict(H.synth_sd(meta), strict=True)
+    finalize(mod, device)
+    g = torch.Generator().manual_seed(5)
+    wav = 0.1 * torch.randn(6400 + 37, generator=g) + 0.2 * torch.sin(torch.arange(6437) * 0.05)   # off the hop grid
+    out = denoise(wav.to(device), mod, H.DENOISER_H).cpu()
+    norm = torch.sqrt(len(wav) / torch.sum(wav ** 2.0))
+    mag, pha, _ = mag_pha_stft((wav * norm).unsqueeze(0).to(device), 400, 100, 400, 0.3)
+    ref, _, _ = O.denoise(H.oracle_sd(meta), meta["prefix"], wav, spectrogram=(mag.cpu(), pha.cpu()))
+    assert out.shape == ref.shape == (1, 6400)
+    _close(out.numpy(), ref.numpy(), "denoise end to end")
+    # the module refuses what the reference's call never passes
+    with pytest.raises(L.HspError):
+        denoise(torch.zeros(2, 800, device=device), mod, H.DENOISER_H)
+    with pytest.raises(L.HspError):
+        denoise(torch.zeros(800), mod, H.DENOISER_H)

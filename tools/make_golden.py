@@ -349,19 +349,75 @@ def w2v_cases():
              ref, orc)
 
 
+# ------------------------------------------------------------------- prompt denoiser (N4)
+def denoiser_cases():
+    """denoiser/ (MP-SENet): `denoise` (infer.py:3-10) around `MPNet` (generator.py:118-147).  `pesq` (imported at
+    generator.py:7 for the training-time metric only) is absent from the image and stubbed; the checkpoint
+    `denoiser/g_best` is not in the checkout, so the weights are the synthetic recipe."""
+    import types
+    if "pesq" not in sys.modules:
+        m = types.ModuleType("pesq")
+        m.pesq = lambda *a, **k: 0.0
+        sys.modules["pesq"] = m
+    from denoiser.generator import MPNet, DenseEncoder
+    from denoiser.conformer import ConformerBlock
+    from denoiser.infer import denoise
+    W = 7
+    h = types.SimpleNamespace(dense_channel=64, compress_factor=0.3, num_tsconformers=4, beta=2.0, sampling_rate=16000,
+                              n_fft=400, hop_size=100, win_size=400)
+    # -- one ConformerBlock: attention along dim 0 (nn.MultiheadAttention without batch_first), the rest along dim 1
+    name = "mp_conformer"
+    blk = ConformerBlock(dim=64, n_head=4, ccm_kernel_size=31, ffm_dropout=0.2, attn_dropout=0.2)
+    shapes, sd = load_synth(blk, W, name + ".")
+    x = rnd(301, 13, 40, 64)
+    save(name, dict(kind="mp_conformer", prefix=name, seed=W, shapes=shapes), dict(x=x), blk(t(x)),
+         O.mp_conformer_block(sd, name, t(x)))
+    # -- DenseEncoder on a [1, 2, T, F] input
+    name = "mp_dense_encoder"
+    enc = DenseEncoder(h, in_channel=2)
+    shapes, sd = load_synth(enc, W, name + ".")
+    x = rnd(302, 1, 2, 21, 201)
+    save(name, dict(kind="mp_dense_encoder", prefix=name, seed=W, shapes=shapes), dict(x=x), enc(t(x)),
+         O.mp_dense_encoder(sd, name, t(x)))
+    # -- the whole `denoise` call on 0.5 s and on a 1600-multiple of samples (inference_plm.py:131-133 pads to one)
+    net = MPNet(h)
+    shapes, sd = load_synth(net, W, "")
+    for case, n in [("denoise_l8000", 8000), ("denoise_l14400", 14400)]:
+        tt = np.arange(n) / 16000.0
+        wav = (0.25 * np.sin(2 * np.pi * 190 * tt) * (1 + 0.4 * np.sin(2 * np.pi * 2.5 * tt))
+               + 0.08 * np.random.default_rng(310 + n).standard_normal(n)).astype(np.float32)
+        audio = denoise(t(wav), net, h)
+        amp, pha = None, None
+        o_audio, o_amp, _ = O.denoise(sd, "", t(wav))
+        # the magnitude the network produced, for a second comparison point
+        from denoiser.infer import mag_pha_stft
+        norm = torch.sqrt(len(wav) / torch.sum(t(wav) ** 2.0))
+        a_in, p_in, _ = mag_pha_stft((t(wav) * norm).unsqueeze(0), 400, 100, 400, 0.3)
+        amp, pha, _ = net(a_in, p_in)
+        # the spectrogram the reference run saw travels with the fixture (its edge-frame phase branches are not
+        # reproducible across FFT implementations or even CPUs: oracle.denoise)
+        save(case, dict(kind="denoise", prefix="", seed=W, shapes=shapes),
+             dict(wav=wav, amp_in=a_in.numpy(), pha_in=p_in.numpy()), [audio, amp], [o_audio, o_amp])
+
+
 # ----------------------------------------------------------------------------- cases
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv", "w2v"],
+    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv", "w2v", "denoiser"],
                     help="vocoder: hierspeechpp/attentions/speechsr cases; ttv: ttv_v1 front-end + PLM cases; "
-                         "w2v: the wav2vec2 producer of inference_vc.py")
+                         "w2v: the wav2vec2 producer of inference_vc.py; denoiser: the MP-SENet prompt denoiser")
     args = ap.parse_args()
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
     install_stubs()
     sys.path.insert(0, args.ref)
     os.makedirs(OUT, exist_ok=True)
+    if args.group in ("all", "denoiser"):
+        with torch.no_grad():
+            denoiser_cases()
+    if args.group == "denoiser":
+        return
     if args.group in ("all", "w2v"):
         with torch.no_grad():
             w2v_cases()
