@@ -233,11 +233,9 @@ def run_bench(args, make_workload, backend="nccl", device=None):
 
 # ------------------------------------------------------------------------ roofline (vocoder, live)
 def _build_id():
-    """what the committed PMC traffic file must match: sha256 of the built library"""
-    import hashlib
-    from megatts2_hierspeechpp_amd import _lib as L
-    with open(L.LIB_PATH, "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()[:16]
+    """what the committed PMC traffic file must match: the hash of the kernel sources the library is built from"""
+    from megatts2_hierspeechpp_amd.build import source_id
+    return source_id()
 
 
 def vocoder_roofline(args, wl, result):
@@ -298,8 +296,8 @@ def vocoder_roofline(args, wl, result):
     else:
         with open(path) as fh:
             tj = json.load(fh)
-        if tj.get("lib_sha16") != _build_id():
-            traffic_note, tj = f"profile taken on library {tj.get('lib_sha16')}, this run uses {_build_id()}", None
+        if tj.get("kernel_source_sha16") != _build_id():
+            traffic_note, tj = f"profile taken on kernel sources {tj.get('kernel_source_sha16')}, this run uses {_build_id()}", None
         elif (tj.get("batch_per_gpu"), tj.get("frames")) != (args.batch, wl.frames):
             traffic_note, tj = "profile taken on another workload size", None
         elif tj.get("conv1d_mfma_launches_per_step") != len(mf) or tj.get("act1d_launches_per_step") != len(act_rec):

@@ -18,3 +18,21 @@ def build(verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(verbose=True))
+
+
+def source_id() -> str:
+    """16 hex digits of the sha256 over the kernel sources libhsp.so is built from (csrc/*.hip, csrc/*.h, the
+    Makefile, include/hsp.h): what a committed profile is keyed by -- unlike a hash of the .so it does not depend on
+    where or when the library was compiled."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")))
+    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(root, "include", "hsp.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r02_traffic.json.
-bench.py quotes `roofline.traffic` from that file ONLY when the library hash, the workload size and the launch mix
-recorded here equal the run's own.
+bench.py quotes `roofline.traffic` from that file ONLY when the kernel-source hash, the workload size and the launch mix
+recorded here equal the run's own (the library is identified by the hash of its kernel sources).
 
     python tools/pmc_summarize.py gpurun_out profiles/r02_traffic.json
 
@@ -58,15 +58,16 @@ def three(k):
     return {"raw": f + w, "x2": 2 * f + w, "calibrated": fetch_factor * f + w, "fetch_raw": f, "write_raw": w}
 
 
-with open(os.path.join(ROOT, "megatts2_hierspeechpp_amd", "libhsp.so"), "rb") as fh:
-    sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from megatts2_hierspeechpp_amd.build import source_id  # noqa: E402
+sha = source_id()
 conv = out["conv1d_mfma_kernel"]
 res = {
     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 1 --warmup 0 --no-graph "
             "--no-roofline` (2 executed steps); per kernel class KB as counted.  FETCH calibrated on the step's own "
             "act1d_seg_kernel launches (known bytes: one fp32 read per element); write_check = known / counted write "
             "bytes of the same launches (the guide: WRITE_SIZE is exact for 16-B stores).",
-    "lib_sha16": sha, "batch_per_gpu": B, "frames": T, "steps_in_run": STEPS,
+    "kernel_source_sha16": sha, "batch_per_gpu": B, "frames": T, "steps_in_run": STEPS,
     "fetch_factor": fetch_factor, "write_check": write_check, "kernels": out,
     "conv1d_mfma_launches_per_step": conv["launches"] // STEPS,
     "act1d_launches_per_step": act["launches"] // STEPS,
@@ -77,6 +78,6 @@ for name in ("gemm2_kernel", "tokgemm_kernel"):
     if name in out:
         res[name + "_bytes_per_step"] = three(out[name])
 json.dump(res, open(dst, "w"), indent=1)
-print({k: res[k] for k in ("lib_sha16", "fetch_factor", "write_check", "conv1d_mfma_launches_per_step", "act1d_launches_per_step")})
+print({k: res[k] for k in ("kernel_source_sha16", "fetch_factor", "write_check", "conv1d_mfma_launches_per_step", "act1d_launches_per_step")})
 print("conv1d_mfma GB/step", {k: round(v / 1e9, 2) for k, v in res["conv1d_mfma_bytes_per_step"].items()})
 print("act1d_seg GB/step", {k: round(v / 1e9, 2) for k, v in res["act1d_seg_bytes_per_step"].items()})
