@@ -635,10 +635,32 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
     constexpr int rowB = 2 * C::XWP * 4;   // bytes: next channel pair in the window
     const int spanB = (KC >> 1) * rowB;    // all pairs of one tap
     const int tapB = 4 * a.dil;
+    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    };
+    // The fragment pipeline runs ACROSS chunks: the barrier that hands over chunk c+1 sits between the last two
+    // MFMA groups of chunk c (all LDS reads of chunk c are retired by then - its last fragments are in registers),
+    // and the first fragments of chunk c+1 are requested right behind it, under the last MFMA group of chunk c.
+    // With the barrier after the last group the first reads of every chunk were exposed (~3 % at 22-28 steps per
+    // chunk).  Barrier count is unchanged: one before the loop, one per chunk.
+    unsigned aA = lds_addr(lds + wlane);                 // per-lane LDS byte addresses of the chunk's buffers
+    unsigned aB = lds_addr(lds + P.xa_off + xlane);
+    unsigned va = aA, vb = aB;
+    const bool run = !HSP_DBG(a, 2);
+    if (run) {
+      ds_read_frags<TM>(fa0, va);
+      ds_read_frags<TN>(fb0, vb);
+    }
     for (int c = 0; c < nchunks; ++c) {
-      const int cb = c & 1;
-      const unsigned aA = lds_addr(lds + cb * P.ws_sz + wlane);           // per-lane LDS byte addresses
-      const unsigned aB = lds_addr(lds + P.xa_off + cb * P.xa_sz + xlane);
+      if (!run) {
+        HSP_BARRIER(a);
+        continue;
+      }
       int offA = 0, pairB = 0, tapoff = 0;  // scalar byte offsets of the current trip
       auto advance = [&]() __attribute__((always_inline)) {
         int t;
@@ -653,31 +675,22 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
             : [sa] "n"(2 * kStepA), [sb] "n"(2 * rowB), [span] "s"(spanB), [tap] "s"(tapB)
             : "scc");
       };
-      float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-      auto mma_set = [&](const float (&fa)[TM], const float (&fb)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[n], acc[i][n], 0, 0, 0);
-      };
-      unsigned va = aA, vb = aB;
-      ds_read_frags<TM>(fa0, va);
-      ds_read_frags<TN>(fb0, vb);
-      for (int s = HSP_DBG(a, 2) ? nsteps : 0; s < nsteps; s += 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s fragments have landed
+      // first slot of a trip: the second step of the same tap, through immediates
+      auto slot_a = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the first step's fragments have landed
         __builtin_amdgcn_sched_barrier(0);
-        // step s+1: same tap, next pair
         ds_read_frags_at<TM, kStepA>(fa1, va);
         ds_read_frags_at<TN, rowB>(fb1, vb);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
         mma_set(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);  // or the MFMAs sink below the next wait, which then follows its reads at once
-        advance();  // step s+2; past the end on the last trip -> re-read step 0 (unused)
-        const bool more = s + 2 < nsteps;
-        va = aA + (unsigned)(more ? offA : 0);
-        vb = aB + (unsigned)(more ? pairB + tapoff : 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step s+1 fragments have landed
+      };
+      for (int s = 0; s + 2 < nsteps; s += 2) {   // every trip but the last
+        slot_a();
+        advance();
+        va = aA + (unsigned)offA;
+        vb = aB + (unsigned)(pairB + tapoff);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the second step's fragments have landed
         __builtin_amdgcn_sched_barrier(0);
         ds_read_frags<TM>(fa0, va);
         ds_read_frags<TN>(fb0, vb);
@@ -685,7 +698,21 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
         mma_set(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      HSP_BARRIER(a);
+      slot_a();                                    // last trip, first step
+      HSP_BARRIER(a);                              // (waits lgkmcnt(0) first) chunk c+1 is staged, chunk c's buffer is free
+      if (c + 1 < nchunks) {
+        const int nb = (c + 1) & 1;
+        aA = lds_addr(lds + nb * P.ws_sz + wlane);
+        aB = lds_addr(lds + P.xa_off + nb * P.xa_sz + xlane);
+        va = aA;
+        vb = aB;
+        __builtin_amdgcn_sched_barrier(0);
+        ds_read_frags<TM>(fa0, va);                // chunk c+1, step 0
+        ds_read_frags<TN>(fb0, vb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_set(fa1, fb1);                           // last step of chunk c, over the barrier's wake-up and the new reads
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
