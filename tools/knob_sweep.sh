@@ -4,6 +4,3 @@ run() { echo -n "$*: "; env "$@" timeout -k 10 200 python bench.py --steps 5 --w
 run HSP_FRONT_SPLITS=4
 run HSP_FRONT_SPLITS=2
 run HSP_FRONT_SPLITS=1
-run HSP_FRONT_SPLITS=4 HSP_CONV_DEBUG=32768
-run HSP_FRONT_SPLITS=2 HSP_CONV_DEBUG=32768
-run HSP_FRONT_SPLITS=1 HSP_CONV_DEBUG=32768
