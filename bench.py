@@ -24,7 +24,8 @@ Printed JSON (one line, rank 0): metric/value per the driver contract plus
                    taken on this very build and launch mix, else null with the reason
   cpu_baseline  -- the CPU oracle (oracle/hsp_oracle.py) on this box's host cores: configs[0] (1 x 1 s) and a
                    bounded sample of configs[1] (8 x 4 s), N=1 only
-  extra_configs -- configs[2] (full text->wav, batch 16) and configs[3] (vocoder + SpeechSR48, batch 32),
+  extra_configs -- configs[0] on the GPU (1 x 1 s latency), configs[2] (full text->wav, batch 16) and configs[3]
+                   (vocoder + SpeechSR48, batch 32),
                    N=1 only (tools/bench_extra.py)
 """
 import argparse
@@ -419,6 +420,7 @@ def main(argv=None):
         if result["n_gpus"] == 1 and not args.no_extra:
             from tools import bench_extra
             extra = {}
+            extra["vocoder_b1_1s"] = bench_extra.vocoder_b1_1s(wl.dev, steps=20, net=wl.model)
             extra["sr48_b32"] = bench_extra.sr48_b32(wl.dev, steps=5, net=wl.model)
             del wl
             extra["tts_b16"] = bench_extra.tts_b16(torch_device(), steps=3)

@@ -171,6 +171,38 @@ def tts_b16(dev, steps=3, warmup=1, batch=16, phones=40, use_graph=True, models=
 
 
 # ----------------------------------------------------------------------------- configs[3]
+def vocoder_b1_1s(dev, steps=20, net=None):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case: vocoder-only infer(), 1 utterance x 1 s) on
+    the GPU: the latency of one small request, hipGraph replay.  bench.py's cpu_baseline times the same case on the
+    host (config0_1x1s)."""
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
+    if net is None:
+        net = SynthesizerTrn(641, 192, **VOC_CFG)
+        net.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0))
+                             for k, v in net.state_dict().items()})
+        net.finalize(dev)
+    B, T = 1, 50
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_inputs(B, T, seed=2).items()}
+
+    def step():
+        return net.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])[0]
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o = step()
+    g.replay()
+    torch.cuda.synchronize()
+    ms = event_median_ms(g.replay, steps)
+    assert o.shape == (B, 1, 320 * T) and bool(torch.isfinite(o).all())
+    return {"metric": "latency of vocoder-only infer(), 1 utterance x 1 s (BASELINE.json configs[0])",
+            "value": B * 320 * T / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms, "rtf": ms * 1e-3 / 1.0,
+            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
+            "config": {"workload": "vocoder infer() 1 x 1 s (50 frames)", "launch_mode": "hipGraph replay, median of HIP-event pairs"}}
+
+
 def sr48_b32(dev, steps=5, batch=32, net=None):
     """vocoder (32 x 4 s) -> SpeechSR48: 48 kHz output samples / s of the two-stage pipeline, hipGraph replay."""
     from megatts2_hierspeechpp_amd import synth
