@@ -151,6 +151,43 @@ def test_direct_conv_vs_torch(cin, cout, k, stride, dil, L, device):
     _close(got, ref, "direct")
 
 
+@pytest.mark.parametrize("cin,cout,k,dil,pad,L,B", [
+    (96, 80, 5, 20, 40, 333, 2),        # halo 80 > 61 columns: the wide-window shape (S64W)
+    (256, 256, 11, 5, 25, 1111, 2),     # 128 x 128 tiles, 64 chunks of 11 trips, ragged last column tile
+    (256, 256, 7, 3, 9, 777, 3),        # 14 trips per chunk
+    (128, 128, 3, 1, 1, 4099, 2),       # 12 trips per chunk, L % 4 != 0: 4-B window DMA
+    (12, 40, 1, 1, 0, 700, 3),          # one trip per chunk (KC = 4, k = 1): the trip loop runs zero times
+    (64, 64, 2, 1, 1, 500, 2),          # even kernel: one output more than inputs
+    (40, 72, 9, 2, 8, 130, 33),         # many short rows: few big tiles -> 64 x 64 tiles
+    (32, 32, 11, 1, 5, 5000, 2),        # 32 x 512 tiles
+])
+def test_mfma_conv_vs_torch(cin, cout, k, dil, pad, L, B, device):
+    """hsp_conv1d_mfma_f32 against torch's conv1d on CPU over the tile shapes and chunk geometries of the consumer loop
+    (tap-outer walk, trips of two k-steps, fragment pipeline across chunks), plain and with the accumulator-init
+    operands (residual + running sum + post-scale) on strided batch views."""
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    mod = Conv1d(cin, cout, k, padding=pad, dilation=dil)
+    g = torch.Generator().manual_seed(k * 131 + cin)
+    mod.weight.data = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    mod.bias.data = torch.randn(cout, generator=g) * 0.1
+    finalize(mod, device)
+    x = torch.randn(B, cin, L, generator=g)
+    ref = torch.nn.functional.conv1d(x, mod.weight.data.cpu(), mod.bias.data.cpu(), 1, pad, dil)
+    got = mod(x.to(device))
+    _close(got.cpu().numpy(), ref.numpy(), "plain")
+    # residual + accumulate + post_scale, input and output as row slices of wider buffers (non-contiguous batch stride)
+    Lo = ref.shape[2]
+    xb = torch.randn(B, cin + 8, L, generator=g)
+    res = torch.randn(B, cout, Lo, generator=g)
+    acc = torch.randn(B, cout + 4, Lo, generator=g)
+    ref2 = (torch.nn.functional.conv1d(xb[:, 4:4 + cin], mod.weight.data.cpu(), mod.bias.data.cpu(), 1, pad, dil) + res
+            + acc[:, 2:2 + cout]) * 0.5
+    acc_d = acc.to(device)
+    mod(xb.to(device)[:, 4:4 + cin], res=res.to(device), out=acc_d[:, 2:2 + cout], accumulate=True, post_scale=0.5)
+    _close(acc_d[:, 2:2 + cout].cpu().numpy(), ref2.numpy(), "res + accumulate")
+    assert torch.equal(acc_d[:, :2].cpu(), acc[:, :2]) and torch.equal(acc_d[:, 2 + cout:].cpu(), acc[:, 2 + cout:])
+
+
 def test_wn_and_attention_longer_ragged(device):
     """WN (gated MFMA epilogue) and the DiT block (LayerNorm + attention + conv FFN) at
     T = 333 with ragged lengths: more than one tile per utterance, masked tails."""
