@@ -56,7 +56,11 @@ def finalize_distributed(model, device, src: int = 0):
     """Rank ``src`` folds + packs the weights; every other rank only lays the arena out
     (identical offsets by construction) and receives the bytes by broadcast."""
     rank = dist.get_rank() if dist.is_initialized() else 0
-    arena = model.finalize(device, materialize=(rank == src))
+    res = model.finalize(device, materialize=(rank == src))
+    # hip_layers.finalize leaves the arena on the model whatever the model's own finalize() returns (some return self)
+    arena = getattr(model, "_hsp_arena", None)
+    if arena is None:
+        arena = res
     broadcast_buffer(arena.buffer, src)
     return arena
 

@@ -280,6 +280,41 @@ def test_full_size_one_utterance_vs_oracle(full_model, device):
     _close(ge.cpu().numpy(), re_.numpy(), "infer 1x4s source")
 
 
+def test_layout_only_rank_reproduces_rank0(device):
+    """What a rank other than the broadcast source does in a multi-GPU job (parallel.finalize_distributed): lay the
+    weight arena out without the weights (materialize=False), receive rank 0's bytes, run.  Emulated in one process
+    by copying the arena buffer; the outputs must equal rank 0's bit for bit.  Covers the vocoder (weight-norm folds,
+    polyphase ConvTranspose packs, fused pairs), the SpeechSR head and the denoiser (sub-layers that live inside other
+    layers and are filled from their parents' parameters)."""
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.denoiser.generator import MPNet
+    from megatts2_hierspeechpp_amd.denoiser.infer import denoise
+    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
+    from oracle.hsp_oracle import default_config
+
+    def pair(make):
+        a, b = make(), make()
+        a.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 11)) for k, v in a.state_dict().items()})
+        a.finalize(device)
+        b.finalize(device, materialize=False)              # zero / default parameters: nothing may be read from them
+        ar_a, ar_b = a._hsp_arena, b._hsp_arena
+        assert ar_a.total == ar_b.total and [sp[1:] for sp in ar_a.specs] == [sp[1:] for sp in ar_b.specs]
+        ar_b.buffer.copy_(ar_a.buffer)                     # the RCCL broadcast
+        return a, b
+
+    voc_a, voc_b = pair(lambda: SynthesizerTrn(641, 192, **default_config()))
+    inp = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_inputs(2, 24, seed=4).items()}
+    args = (inp["mel"], inp["w2v"], inp["length"], inp["f0"])
+    oa, ea = voc_a.infer(*args, noise=inp["noise"])
+    ob, eb = voc_b.infer(*args, noise=inp["noise"])
+    assert torch.equal(oa, ob) and torch.equal(ea, eb)
+
+    den_a, den_b = pair(lambda: MPNet(H.DENOISER_H))
+    g = torch.Generator().manual_seed(12)
+    wav = (0.1 * torch.randn(4000, generator=g)).to(device)
+    assert torch.equal(denoise(wav, den_a, H.DENOISER_H), denoise(wav, den_b, H.DENOISER_H))
+
+
 def test_conv_linearity_full_width(device):
     """conv(a*x + b*y) == a*conv(x) + b*conv(y) for the plain MFMA conv at a stage-2 shape."""
     from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
