@@ -4,7 +4,9 @@ arguments and state-dict keys (reference: modules.py).  Every tensor stays chann
 changes only.  All arithmetic is in libhsp.so."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -15,6 +17,19 @@ from . import hip_layers
 from .hip_layers import Conv1d, HipLayer, Linear
 
 LRELU_SLOPE = 0.1  # modules.py:17
+
+# The one-launch WN layer / DiT FFN (csrc/hsp_gemm2.hip) is a serial chain of ~150 weight chunks per 32-column tile:
+# ~110 / ~200 us per launch however few tiles there are.  It pays when ONE launch has enough tiles to occupy the chip
+# (32 utterances x 200 frames in one group = 200 tiles: 85.0 ms per step against 87.2 with separate launches).  The
+# vocoder's front part runs as four batch groups on four streams by default, and there the separate, shorter launches
+# of the groups overlap better than four 50-tile fused launches (83.5 against 84.6 ms); a single short request
+# (1 x 50 frames = 2 tiles) spent 7.3 of its 13.7 ms in these two kernels and takes 9.2 ms without them.
+# 0 = always fuse where the library can.
+FUSE_MIN_TILES = int(os.environ.get("HSP_FUSE_MIN_TILES", "128"))
+
+
+def _fuse(x) -> bool:
+    return x.shape[0] * ((x.shape[2] + 31) // 32) >= FUSE_MIN_TILES
 
 
 class LayerNorm(HipLayer):
@@ -66,18 +81,19 @@ class WN(nn.Module):
             self.res_skip_layers.append(Conv1d(hidden_channels, rs, 1, weight_norm=True))
 
     def forward(self, x, x_mask, g=None, **kwargs):
-        """One hsp_wn_layer_f32 call per layer.  The library runs it as ONE launch where it can (csrc/hsp_gemm2.hip:
-        H = 192, the 50 Hz tensors of the vocoder) and layer by layer otherwise; either way the activations tensor
-        `acts` is only a workspace.  x is never updated in place: the fused kernel's neighbouring column tiles read
+        """One hsp_wn_layer_f32 call per layer when the launch has enough column tiles (FUSE_MIN_TILES).  The library
+        runs it as ONE launch where it can (csrc/hsp_gemm2.hip: H = 192, the 50 Hz tensors of the vocoder) and layer by
+        layer otherwise; either way the activations tensor `acts` is only a workspace.  x is never updated in place: the fused kernel's neighbouring column tiles read
         the old x as their halo."""
         H = self.hidden_channels
         gc = self.cond_layer(g) if g is not None else None  # [B, 2H*n, 1]
         out = None
         acts = torch.empty(x.shape[0], H, x.shape[2], dtype=torch.float32, device=x.device)
+        fuse = _fuse(x)
         for i in range(self.n_layers):
             cb = gc[:, 2 * H * i: 2 * H * (i + 1)] if gc is not None else None
             last = i == self.n_layers - 1
-            with hip_layers.deferred() as args:
+            with (hip_layers.deferred() if fuse else contextlib.nullcontext()) as args:
                 self.in_layers[i](x, cbias=cb, out=acts)
                 if not last:
                     x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
@@ -85,8 +101,9 @@ class WN(nn.Module):
                 else:
                     # last layer: output = output + rs (modules.py:175-176); the final * x_mask follows below
                     out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None)
-            hip_layers.launch_group("hsp_wn_layer_f32", L.lib().hsp_wn_layer_f32,
-                                    [args[0], args[1] if not last else None, args[-1]])
+            if fuse:
+                hip_layers.launch_group("hsp_wn_layer_f32", L.lib().hsp_wn_layer_f32,
+                                        [args[0], args[1] if not last else None, args[-1]])
             if not last:
                 x = x_new
         return Fh.mask_mul(out, x_mask)
@@ -159,10 +176,12 @@ class DiTConVBlock(nn.Module):
         h = Fh.layernorm_mod(x, 1e-6, shift=sh_m, scale=sc_m)
         # fc1 -> GELU -> fc2 as ONE hsp_ffn_conv_f32 call (one launch where the library has the fused kernel);
         # fc2(y * mask) * mask == (W y + b) * mask for a 1x1 conv and a 0/1 mask
-        with hip_layers.deferred() as args:
+        fuse = _fuse(x)
+        with (hip_layers.deferred() if fuse else contextlib.nullcontext()) as args:
             y = self.mlp.fc1(h, act=L.ACT_GELU_TANH)
             out = self.mlp.fc2(y, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_m, res=x)
-        hip_layers.launch_group("hsp_ffn_conv_f32", L.lib().hsp_ffn_conv_f32, args)
+        if fuse:
+            hip_layers.launch_group("hsp_ffn_conv_f32", L.lib().hsp_ffn_conv_f32, args)
         return out
 
 

@@ -31,6 +31,26 @@ def test_golden(name, device):
         _close(o, r, f"{name}[{i}]")
 
 
+@pytest.mark.parametrize("name", ["wn_h192", "dit_block", "coupling", "flow", "posterior_sf", "infer_config1", "infer_ragged",
+                                  "vc_noise_control", "vc_plain"])
+def test_golden_through_the_fused_two_gemm_kernel(name, device, monkeypatch):
+    """The golden cases are a few tiles wide, below the tile count at which the host mirror chooses the one-launch WN
+    layer / DiT FFN (modules.FUSE_MIN_TILES): here every such layer is forced through csrc/hsp_gemm2.hip and must meet
+    the same reference outputs; the separate-launch path is what test_golden runs."""
+    from megatts2_hierspeechpp_amd import hip_layers, modules
+    if name not in H.fixture_names():
+        pytest.skip(f"no fixture {name}")
+    calls = []
+    orig = hip_layers.launch_group
+    monkeypatch.setattr(modules, "FUSE_MIN_TILES", 0)
+    monkeypatch.setattr(hip_layers, "launch_group", lambda kind, *a, **k: (calls.append(kind), orig(kind, *a, **k))[1])
+    meta, arrays = H.load_fixture(name)
+    outs = H.run_hip(meta, arrays, device)
+    assert calls, "no fused launch was issued"
+    for i, (o, r) in enumerate(zip(outs, H.outputs(arrays))):
+        _close(o, r, f"{name}[{i}] (fused)")
+
+
 @pytest.mark.parametrize("name", ["wn_h192", "dit_block", "convtr_k11_s5", "generator", "infer_ragged"])
 def test_survey_abi_names_give_identical_results(name, device):
     """The dispatching entry points named in SURVEY.md §8(b) (hsp_conv1d_f32, hsp_convtr1d_f32, hsp_wn_layer_f32,

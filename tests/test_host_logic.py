@@ -301,6 +301,7 @@ def test_vocoder_wn_layers_and_dit_ffn_take_the_one_launch_path(monkeypatch):
         seen.append((kind, lib.hsp_fused_pair_supported(first, second, third)))
 
     monkeypatch.setattr(HL, "launch_group", fake_group)
+    monkeypatch.setattr(M, "FUSE_MIN_TILES", 0)          # the tile-count policy is tested below
     monkeypatch.setattr(M.Fh, "mask_mul", lambda x, m: x)
     monkeypatch.setattr(M.Fh, "layernorm_mod", lambda x, *a, **k: torch.empty_like(x))
     monkeypatch.setattr(M.Fh, "mha", lambda q, k, v, *a, **kw: torch.empty_like(q))
@@ -326,3 +327,11 @@ def test_vocoder_wn_layers_and_dit_ffn_take_the_one_launch_path(monkeypatch):
             m._w, m._b = torch.zeros(m.k * m.cin * m.M), torch.zeros(m.cout)
     wn512(torch.zeros(2, 512, 200), torch.ones(2, 1, 200))
     assert [ok for _, ok in seen] == [0, 0]
+    # policy of the host mirror: a launch with fewer than FUSE_MIN_TILES 32-column tiles issues the separate launches
+    # (a fused launch is a ~200 us serial chain per tile however few tiles there are)
+    monkeypatch.setattr(M, "FUSE_MIN_TILES", 32)
+    assert M._fuse(torch.zeros(32, 192, 200)) and M._fuse(torch.zeros(8, 192, 200)) and M._fuse(torch.zeros(1, 192, 1024))
+    assert not M._fuse(torch.zeros(1, 192, 50)) and not M._fuse(torch.zeros(4, 192, 200))
+    seen.clear()
+    wn(torch.zeros(1, 192, 50), torch.ones(1, 1, 50))
+    assert seen == []
