@@ -254,7 +254,9 @@ int hsp_layernorm_mod_f32(const float* x, float* y, int32_t B, int32_t C, int32_
  * [B, H*D, T] views (strides in elements).  mask, if given, is the key/query validity
  * [B, T]: scores where mask_q*mask_k == 0 are set to -1e4 (attentions.py:174-175).
  * Without mask: timm 0.6.13 Attention (modules.py:409).  Optional relative-position
- * window (emb_rel_k/v [2w+1, D]): attentions.py:165-170,183-186. */
+ * window (emb_rel_k/v [2w+1, D]): attentions.py:165-170,183-186.
+ * No length ceiling: score rows that do not fit the CU's LDS are walked in key blocks with an online softmax
+ * (head dim <= 128 without a window, <= 256 with one). */
 typedef struct hsp_mha_args {
   const float *q, *k, *v;
   float* o;
@@ -265,10 +267,15 @@ typedef struct hsp_mha_args {
   const float* mask_k; /* [B, Tq], [B, Tk] or NULL */
   const float* rel_k;
   const float* rel_v;
-  int32_t window;
+  int32_t window;                 /* w > 0 with rel_k / rel_v.  Negative = test hook: -(w + 1) forces the key-streaming
+                                     kernels (which otherwise serve only the lengths the whole-row kernels cannot hold) */
   int64_t q_cs, k_cs, v_cs, o_cs; /* channel strides; 0 = contiguous rows (Tq / Tk).  A larger stride lets the
                                      utterances of a batch sit side by side on the column axis of one
                                      [C][B*T] matrix (batch stride T): the layout of the PLM loop */
+  const float* mask_dense;        /* optional [B][Tq][Tk] (batch stride mask_dense_bs >= Tq * Tk, shared by the heads):
+                                     the reference's general ``attn_mask`` (attentions.py:147-155,174-175): scores where
+                                     it is 0 become -1e4.  NULL = none.  May be combined with mask_q / mask_k. */
+  int64_t mask_dense_bs;
 } hsp_mha_args;
 int hsp_mha_f32(const hsp_mha_args* a, void* stream);
 /* out[b, c] = sum_t x[b, c, t] / sum_t mask[b, t] : styleencoder.py:83-91 */

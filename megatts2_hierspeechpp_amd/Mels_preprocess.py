@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .hip_layers import Conv1d, finalize as _finalize
+from .hip_layers import Conv1d, entry as _entry, finalize as _finalize
 
 
 def melscale_fbanks_htk(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> np.ndarray:
@@ -76,6 +76,7 @@ class MelSpectrogramFixed(nn.Module):
         self._lo, self._hi = torch.from_numpy(lo).to(device), torch.from_numpy(hi).to(device)
         return self
 
+    @_entry
     @torch.no_grad()
     def forward(self, x):
         """x [..., L] fp32 on the GPU (L > n_fft / 2) -> log-mel [..., n_mels, L // hop_length]."""

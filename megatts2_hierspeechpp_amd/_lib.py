@@ -57,6 +57,7 @@ class MhaArgs(C.Structure):
         ("qk_scale", C.c_float),
         ("mask_q", _fp), ("mask_k", _fp), ("rel_k", _fp), ("rel_v", _fp), ("window", C.c_int32),
         ("q_cs", C.c_int64), ("k_cs", C.c_int64), ("v_cs", C.c_int64), ("o_cs", C.c_int64),
+        ("mask_dense", _fp), ("mask_dense_bs", C.c_int64),
     ]
 
 

@@ -96,13 +96,14 @@ class MultiHeadAttention(HipLayer):
             self._rv.copy_(self.emb_rel_v.data.reshape(-1))
 
     def forward(self, x, c, attn_mask=None, *, mask_q=None, mask_k=None, res=None, cbias=None, out=None):
-        """``attn_mask`` of the reference is always mask_k[b, j] * mask_q[b, i]
-        (attentions.py:39, styleencoder.py:71); pass the two [B, 1, T] factors."""
-        if attn_mask is not None:
-            raise NotImplementedError("pass mask_q / mask_k ([B,1,T]) instead of the outer-product attn_mask")
+        """The reference's signature ``forward(x, c, attn_mask=None)`` (attentions.py:147-155): ``attn_mask``
+        [B, 1, Tq, Tk] (bool or float, 0 = masked, shared by the heads) is applied element by element inside the
+        attention kernel (hsp_mha_args.mask_dense).  The mirrors' own call sites pass the two [B, 1, T] factors
+        ``mask_q`` / ``mask_k`` instead -- the reference's masks are always that outer product (attentions.py:39,
+        styleencoder.py:71) -- which saves building and reading the [Tq, Tk] matrix."""
         q, k, v = self.conv_q(x), self.conv_k(c), self.conv_v(c)
         rel_k = self._rk if self.window_size is not None else None
         rel_v = self._rv if self.window_size is not None else None
         o = Fh.mha(q, k, v, self.n_heads, 1.0 / math.sqrt(self.k_channels), mask_q=mask_q, mask_k=mask_k,
-                   rel_k=rel_k, rel_v=rel_v, window=self.window_size or 0)
+                   rel_k=rel_k, rel_v=rel_v, window=self.window_size or 0, mask_dense=attn_mask)
         return self.conv_o(o, res=res, cbias=cbias, out=out)

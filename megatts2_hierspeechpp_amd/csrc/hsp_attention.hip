@@ -4,11 +4,10 @@
 // mask, scale D^-0.5), and attentions.MultiHeadAttention (attentions.py:157-188:
 // masked_fill(mask == 0, -1e4), optional relative-position window on keys and values).
 //
-// One workgroup = 16 queries of one (batch, head).  Scores for all keys are kept in
-// LDS (16 x Tk), soft-maxed by rows, then multiplied with V, which is streamed through
-// LDS in 64-key slabs transposed so that lanes run along the head dimension.
-// Round-1 implementation on the vector pipe: T <= a few hundred on this path (50 Hz
-// frames), the whole attention work is ~10 % of the vocoder FLOPs.
+// Whole-row kernels (mha_kernel, mha_mfma_kernel): one workgroup = 16 / 32 queries of one (batch, head), the
+// scores for ALL keys are kept in LDS, soft-maxed by rows, then multiplied with V.  They serve every launch
+// whose score rows fit the CU's LDS (T <= a few hundred on the 50 Hz path); beyond that the key-streaming
+// kernels at the end of this file (online softmax over key blocks) take over, so no launch has a length ceiling.
 #include <atomic>
 #include "hsp_device.h"
 
@@ -73,6 +72,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_kernel(const hsp_mha_args a, 
         if (a.mask_q && i < Tq) {
           if (a.mask_q[(int64_t)b * Tq + i] * a.mask_k[(int64_t)b * Tk + j] == 0.0f) s = -1e4f;
         }
+        if (a.mask_dense && i < Tq && a.mask_dense[(int64_t)b * a.mask_dense_bs + (int64_t)i * Tk + j] == 0.0f) s = -1e4f;
         S[(iq + u) * spad + j] = s;
       }
     }
@@ -230,10 +230,12 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const hsp_mha_args a, int
     float* row = S + row_i * sp;
     const int i = i0 + row_i;
     const float mq = (a.mask_q && i < Tq) ? a.mask_q[(int64_t)b * Tq + i] : 1.0f;
+    const float* md = (a.mask_dense && i < Tq) ? a.mask_dense + (int64_t)b * a.mask_dense_bs + (int64_t)i * Tk : nullptr;
     float mx = -3.0e38f;
     for (int j = lane; j < Tk; j += 64) {
       float sv = row[j];
       if (a.mask_q && mq * a.mask_k[(int64_t)b * Tk + j] == 0.0f) sv = -1e4f;
+      if (md && md[j] == 0.0f) sv = -1e4f;
       row[j] = sv;
       mx = fmaxf(mx, sv);
     }
@@ -316,6 +318,321 @@ int mha_mfma_launch(const hsp_mha_args& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Key-streaming variants (online softmax): no launch depends on Tk fitting LDS.  Used when the whole-row kernels
+// above would need more than the CU's 160 KB (Tk beyond ~1 200 with the MFMA kernel, ~2 200 with the window
+// kernel): the denoiser's time conformer on a long prompt (160 frames/s, denoiser/conformer.py:45-60), the
+// StyleEncoder / MelEncoder on a minute of mel frames (attentions.py:157-188).  Keys are walked in blocks; a query
+// row keeps a running maximum m and sum l, and the PV accumulators are rescaled by exp(m_old - m_new) whenever the
+// maximum moves.  masked_fill(-1e4) semantics are unchanged: a masked score is the VALUE -1e4 (a fully masked row
+// ends as the uniform average, as in the reference); only keys beyond Tk are excluded (weight 0).
+constexpr int SKB = 128;   // keys per block of the MFMA kernel (4 waves x 32)
+
+template <int NDB>
+__global__ __launch_bounds__(256) void mha_mfma_stream_kernel(const hsp_mha_args a, int n_qt) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = a.D, Tq = a.Tq, Tk = a.Tk;
+  constexpr int DP = NDB * 32;
+  constexpr int SP = SKB + 1, VP = SKB + 1;
+  float* Qs = lds;                 // [DP][32]  scale * q, zero rows beyond D
+  float* S = Qs + DP * 32;         // [32][SP]
+  float* Vs = S + 32 * SP;         // [DP][VP]
+  float* mrow = Vs + DP * VP;      // [32] running maximum
+  float* lrow = mrow + 32;         // [32] running sum
+  float* arow = lrow + 32;         // [32] rescale factor of the current block
+  int bid = blockIdx.x;
+  const int qt = bid % n_qt;
+  bid /= n_qt;
+  const int h = bid % a.H;
+  const int b = bid / a.H;
+  const int i0 = qt * MQT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int64_t qcs = a.q_cs, kcs = a.k_cs, vcs = a.v_cs, ocs = a.o_cs;
+  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * qcs;
+  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * kcs;
+  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
+  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
+
+#pragma unroll
+  for (int u = 0; u < DP * 32 / 256; ++u) {
+    const int e = tid + 256 * u;
+    const int i = e & 31, d = e >> 5;
+    Qs[e] = (d < D && i0 + i < Tq) ? qh[(int64_t)d * qcs + i0 + i] * a.qk_scale : 0.0f;
+  }
+  if (tid < 32) { mrow[tid] = -3.0e38f; lrow[tid] = 0.0f; }
+  mha_f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
+
+  for (int j0 = 0; j0 < Tk; j0 += SKB) {
+    __syncthreads();   // Q / state initialised (first block); S and Vs of the previous block consumed
+    // V block -> LDS (zero beyond Tk and beyond D)
+    for (int d = wave; d < DP; d += 4)
+      for (int jj = lane; jj < SKB; jj += 64)
+        Vs[d * VP + jj] = (d < D && j0 + jj < Tk) ? vh[(int64_t)d * vcs + j0 + jj] : 0.0f;
+    // scores of this wave's 32 keys
+    {
+      const int j = j0 + wave * 32 + l32;
+      const bool jok = j < Tk;
+      float kf[DP / 2];
+#pragma unroll
+      for (int kk = 0; kk < DP / 2; ++kk) {
+        const int d = 2 * kk + half;
+        kf[kk] = (jok && d < D) ? kh[(int64_t)d * kcs + j] : 0.0f;
+      }
+      mha_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < DP / 2; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(2 * kk + half) * 32 + l32], kf[kk], acc, 0, 0, 0);
+      const float mk = (a.mask_k && jok) ? a.mask_k[(int64_t)b * Tk + j] : 1.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row_i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int i = i0 + row_i;
+        float sv = acc[r];
+        if (i < Tq && jok) {
+          if (a.mask_q && a.mask_q[(int64_t)b * Tq + i] * mk == 0.0f) sv = -1e4f;
+          if (a.mask_dense && a.mask_dense[(int64_t)b * a.mask_dense_bs + (int64_t)i * Tk + j] == 0.0f) sv = -1e4f;
+        }
+        S[row_i * SP + wave * 32 + l32] = jok ? sv : -3.0e38f;
+      }
+    }
+    __syncthreads();
+    // online softmax of rows 8 wave .. 8 wave + 7 over the block's 128 columns (two per lane)
+    for (int u = 0; u < 8; ++u) {
+      const int row_i = wave * 8 + u;
+      float* row = S + row_i * SP;
+      const float s0 = row[lane], s1 = row[lane + 64];
+      float mx = fmaxf(s0, s1);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mo = mrow[row_i];
+      const float mn = fmaxf(mo, mx);
+      const float e0 = s0 > -1.0e38f ? __builtin_amdgcn_exp2f((s0 - mn) * 1.4426950408889634f) : 0.0f;
+      const float e1 = s1 > -1.0e38f ? __builtin_amdgcn_exp2f((s1 - mn) * 1.4426950408889634f) : 0.0f;
+      row[lane] = e0;
+      row[lane + 64] = e1;
+      float sum = e0 + e1;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (lane == 0) {
+        const float al = __builtin_amdgcn_exp2f((mo - mn) * 1.4426950408889634f);   // 0 on the first block
+        arow[row_i] = al;
+        lrow[row_i] = lrow[row_i] * al + sum;
+        mrow[row_i] = mn;
+      }
+    }
+    __syncthreads();
+    // O^T += V P^T on the rescaled accumulators: wave w owns head-dim block w, queries sit on the lanes
+    if (wave < NDB) {
+      const float al = arow[l32];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= al;
+      const float* va = Vs + (wave * 32 + l32) * VP + half;
+      const float* pb = S + l32 * SP + half;
+#pragma unroll 8
+      for (int jj = 0; jj < SKB; jj += 2) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[jj], pb[jj], oacc, 0, 0, 0);
+    }
+  }
+  if (wave < NDB && i0 + l32 < Tq) {
+    const float inv = 1.0f / lrow[l32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = oacc[r] * inv;
+    }
+  }
+}
+
+template <int NDB>
+int mha_mfma_stream_launch(const hsp_mha_args& a, hipStream_t stream) {
+  constexpr int DP = NDB * 32;
+  const size_t lds_bytes = ((size_t)DP * 32 + 32 * (SKB + 1) + (size_t)DP * (SKB + 1) + 96) * sizeof(float);
+  const int n_qt = (a.Tq + MQT - 1) / MQT;
+  const int64_t blocks = (int64_t)n_qt * a.H * a.B;
+  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
+  static hsp_lds_flags flags;
+  if (lds_bytes > 32 * 1024)
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_mfma_stream_kernel<NDB>), (int)lds_bytes, flags)) return e;
+  hipLaunchKernelGGL((mha_mfma_stream_kernel<NDB>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a, n_qt);
+  return (int)hipGetLastError();
+}
+
+// Window (relative-position) kernel, key-streaming form.  Same thread roles as mha_kernel: wave w scores
+// queries 4w .. 4w+3 with lanes along the keys of a block; thread (d, query group) accumulates P V plus the
+// relative-value term of the keys of this block that fall inside a query's window.  D <= 256.
+constexpr int WKB = 256;   // keys per block
+
+__global__ __launch_bounds__(ATT_THREADS) void mha_stream_kernel(const hsp_mha_args a, int n_qt, int dpad) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = a.D, Tq = a.Tq, Tk = a.Tk;
+  constexpr int SPW = WKB + 1;
+  float* Qs = lds;                       // [D][QT]
+  float* S = Qs + D * QT;                // [QT][SPW]
+  float* Vs = S + QT * SPW;              // [64][dpad]
+  float* mrow = Vs + 64 * dpad;          // [QT]
+  float* lrow = mrow + QT;
+  float* arow = lrow + QT;
+  int bid = blockIdx.x;
+  const int qt = bid % n_qt;
+  bid /= n_qt;
+  const int h = bid % a.H;
+  const int b = bid / a.H;
+  const int i0 = qt * QT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t qcs = a.q_cs, kcs = a.k_cs, vcs = a.v_cs, ocs = a.o_cs;
+  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * qcs;
+  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * kcs;
+  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
+  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
+
+  for (int e = tid; e < D * QT; e += ATT_THREADS) {
+    const int i = e % QT, d = e / QT;
+    Qs[e] = (i0 + i < Tq) ? qh[(int64_t)d * qcs + i0 + i] * a.qk_scale : 0.0f;
+  }
+  if (tid < QT) { mrow[tid] = -3.0e38f; lrow[tid] = 0.0f; }
+  const int d = tid & 127, ig = tid >> 7;       // PV role: head dims d and d + 128, queries 8 ig .. 8 ig + 7
+  float acc0[8], acc1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc0[u] = acc1[u] = 0.0f;
+
+  for (int j0 = 0; j0 < Tk; j0 += WKB) {
+    const int jn = min(WKB, Tk - j0);
+    __syncthreads();   // Q / state ready; previous block's S consumed
+    {
+      const int iq = wave * 4;
+      for (int jj = lane; jj < WKB; jj += 64) {
+        const int j = j0 + jj;
+        float sv[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        if (jj < jn) {
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          for (int dd = 0; dd < D; ++dd) {
+            const float kv = kh[(int64_t)dd * kcs + j];
+            const float4 qv = *reinterpret_cast<const float4*>(Qs + dd * QT + iq);
+            s0 = fmaf(qv.x, kv, s0);
+            s1 = fmaf(qv.y, kv, s1);
+            s2 = fmaf(qv.z, kv, s2);
+            s3 = fmaf(qv.w, kv, s3);
+          }
+          sv[0] = s0; sv[1] = s1; sv[2] = s2; sv[3] = s3;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + iq + u;
+            float s = sv[u];
+            if (a.rel_k) {
+              const int r = j - i;
+              if (r >= -a.window && r <= a.window && i < Tq) {
+                const float* ek = a.rel_k + (int64_t)(r + a.window) * D;
+                float t = 0.0f;
+                for (int dd = 0; dd < D; ++dd) t = fmaf(Qs[dd * QT + iq + u], ek[dd], t);
+                s += t;
+              }
+            }
+            if (i < Tq) {
+              if (a.mask_q && a.mask_q[(int64_t)b * Tq + i] * a.mask_k[(int64_t)b * Tk + j] == 0.0f) s = -1e4f;
+              if (a.mask_dense && a.mask_dense[(int64_t)b * a.mask_dense_bs + (int64_t)i * Tk + j] == 0.0f) s = -1e4f;
+            }
+            sv[u] = s;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) S[(iq + u) * SPW + jj] = sv[u];
+      }
+    }
+    __syncthreads();
+    for (int u = 0; u < 4; ++u) {
+      const int row_i = wave * 4 + u;
+      float* row = S + row_i * SPW;
+      float sv[WKB / 64];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int q = 0; q < WKB / 64; ++q) { sv[q] = row[lane + 64 * q]; mx = fmaxf(mx, sv[q]); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mo = mrow[row_i];
+      const float mn = fmaxf(mo, mx);
+      float sum = 0.0f;
+#pragma unroll
+      for (int q = 0; q < WKB / 64; ++q) {
+        const float e = sv[q] > -1.0e38f ? expf(sv[q] - mn) : 0.0f;
+        row[lane + 64 * q] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (lane == 0) {
+        const float al = expf(mo - mn);
+        arow[row_i] = al;
+        lrow[row_i] = lrow[row_i] * al + sum;
+        mrow[row_i] = mn;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const float al = arow[ig * 8 + u]; acc0[u] *= al; acc1[u] *= al; }
+    for (int d0 = 0; d0 < D; d0 += 128) {
+      for (int js = 0; js < jn; js += 64) {
+        __syncthreads();
+        for (int dd = wave; dd < 128 && d0 + dd < D; dd += 4)
+          Vs[lane * dpad + dd] = (js + lane < jn) ? vh[(int64_t)(d0 + dd) * vcs + j0 + js + lane] : 0.0f;
+        __syncthreads();
+        if (d0 + d < D) {
+          const int jm = min(64, jn - js);
+          for (int j = 0; j < jm; ++j) {
+            const float vv = Vs[j * dpad + d];
+            if (d0 == 0) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) acc0[u] = fmaf(S[(ig * 8 + u) * SPW + js + j], vv, acc0[u]);
+            } else {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) acc1[u] = fmaf(S[(ig * 8 + u) * SPW + js + j], vv, acc1[u]);
+            }
+          }
+        }
+      }
+      if (a.rel_v && d0 + d < D) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + ig * 8 + u;
+          if (i >= Tq) continue;
+          float t = 0.0f;
+          for (int r = -a.window; r <= a.window; ++r) {
+            const int j = i + r;
+            if (j >= j0 && j < j0 + jn) t = fmaf(S[(ig * 8 + u) * SPW + j - j0], a.rel_v[(int64_t)(r + a.window) * D + d0 + d], t);
+          }
+          if (d0 == 0) acc0[u] += t; else acc1[u] += t;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = i0 + ig * 8 + u;
+    if (i >= Tq) continue;
+    const float inv = 1.0f / lrow[ig * 8 + u];
+    if (d < D) oh[(int64_t)d * ocs + i] = acc0[u] * inv;
+    if (d + 128 < D) oh[(int64_t)(d + 128) * ocs + i] = acc1[u] * inv;
+  }
+}
+
+int mha_stream_launch(const hsp_mha_args& a, hipStream_t stream) {
+  if (a.D > 256) return HSP_EINVAL;
+  const int n_qt = (a.Tq + QT - 1) / QT;
+  const int dpad = (a.D < 128 ? a.D : 128) | 1;
+  const size_t lds_bytes = ((size_t)a.D * QT + (size_t)QT * (WKB + 1) + 64 * (size_t)dpad + 3 * QT) * sizeof(float);
+  const int64_t blocks = (int64_t)n_qt * a.H * a.B;
+  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
+  static hsp_lds_flags flags;
+  if (lds_bytes > 32 * 1024)
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_stream_kernel), (int)lds_bytes, flags)) return e;
+  hipLaunchKernelGGL(mha_stream_kernel, dim3((unsigned)blocks), dim3(ATT_THREADS), lds_bytes, stream, a, n_qt, dpad);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
@@ -328,24 +645,38 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   if (a.q_cs < a.Tq || a.k_cs < a.Tk || a.v_cs < a.Tk || a.o_cs < a.Tq) return HSP_EINVAL;
   if (!a.q || !a.k || !a.v || !a.o || a.B <= 0 || a.H <= 0 || a.D <= 0 || a.Tq <= 0 || a.Tk <= 0) return HSP_EINVAL;
   if ((a.mask_q == nullptr) != (a.mask_k == nullptr)) return HSP_EINVAL;
+  // test hook: window = -(w + 1) selects the key-streaming kernels at any Tk, with window w
+  const bool force_stream = a.window < 0;
+  if (force_stream) a.window = -(a.window + 1);
   if ((a.rel_k || a.rel_v) && (a.window <= 0 || a.Tq != a.Tk)) return HSP_EINVAL;
-  // matrix-core path: no relative-position window, head dim <= 128, scores of 32 queries fit LDS
+  if (a.mask_dense && a.mask_dense_bs < (int64_t)a.Tq * a.Tk) return HSP_EINVAL;
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  // (the force_stream hook was decoded above, before validation)
+  // matrix-core path: no relative-position window, head dim <= 128.  The whole-row kernel while the scores of 32
+  // queries fit LDS, the key-streaming one (online softmax) beyond
   if (!a.rel_k && !a.rel_v && a.D <= 128) {
-    const hipStream_t st = static_cast<hipStream_t>(stream);
     int e = -1;
-    switch ((a.D + 31) / 32) {
-      case 1: e = mha_mfma_launch<1>(a, st); break;
-      case 2: e = mha_mfma_launch<2>(a, st); break;
-      case 3: e = mha_mfma_launch<3>(a, st); break;
-      default: e = mha_mfma_launch<4>(a, st); break;
+    if (!force_stream) {
+      switch ((a.D + 31) / 32) {
+        case 1: e = mha_mfma_launch<1>(a, st); break;
+        case 2: e = mha_mfma_launch<2>(a, st); break;
+        case 3: e = mha_mfma_launch<3>(a, st); break;
+        default: e = mha_mfma_launch<4>(a, st); break;
+      }
+      if (e >= 0) return e;
     }
-    if (e >= 0) return e;
+    switch ((a.D + 31) / 32) {
+      case 1: return mha_mfma_stream_launch<1>(a, st);
+      case 2: return mha_mfma_stream_launch<2>(a, st);
+      case 3: return mha_mfma_stream_launch<3>(a, st);
+      default: return mha_mfma_stream_launch<4>(a, st);
+    }
   }
   const int n_qt = (a.Tq + QT - 1) / QT;
   const int dpad = (a.D < 128 ? a.D : 128) | 1;
   const int spad = a.Tk + 1;
   const int64_t lds_bytes = ((int64_t)a.D * QT + (int64_t)QT * spad + 64 * dpad) * (int64_t)sizeof(float);
-  if (lds_bytes > 160 * 1024) return HSP_EINVAL;
+  if (lds_bytes > 160 * 1024 || force_stream) return mha_stream_launch(a, st);
   static hsp_lds_flags flags;
   if (lds_bytes > 32 * 1024)
     if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_kernel), 160 * 1024, flags)) return e;

@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import _lib as L
 from .. import functional as Fh
-from ..hip_layers import Conv1d, ConvTranspose1d, HipLayer, PolyphaseConv1d, _SubArena, finalize as _finalize
+from ..hip_layers import Conv1d, ConvTranspose1d, HipLayer, PolyphaseConv1d, _SubArena, entry as _entry, finalize as _finalize
 from .conformer import ConformerBlock
 from .utils import LearnableSigmoid_2d, Vec, get_padding_2d
 
@@ -267,6 +267,7 @@ class MPNet(nn.Module):
         self.arena = _finalize(self, device, materialize)
         return self
 
+    @_entry
     @torch.no_grad()
     def forward(self, noisy_mag, noisy_pha):
         if noisy_mag.dim() != 3 or noisy_mag.shape[0] != 1 or noisy_mag.shape != noisy_pha.shape:

@@ -121,7 +121,11 @@ def denoise(noisy_wav, model, hps):
     x = noisy_wav.contiguous()
     ss = torch.empty(1, dtype=torch.float32, device=x.device)
     L.check(L.lib().hsp_sum_sq_f32(L.fptr(x), x.numel(), L.fptr(ss), L.stream_ptr()), "hsp_sum_sq_f32")
-    norm = math.sqrt(x.numel() / float(ss.item()))
+    ssv = float(ss.item())
+    if not ssv > 0.0:
+        raise L.HspError("denoise(): the prompt is silent (sum of squares 0); the reference's norm factor is inf there "
+                         "and its output NaN")
+    norm = math.sqrt(x.numel() / ssv)
     y = Fh.axpby(x, x, norm, 0.0).unsqueeze(0)
     amp, pha, _ = mag_pha_stft(y, hps.n_fft, hps.hop_size, hps.win_size, hps.compress_factor)
     amp_g, pha_g, _ = model(amp, pha)

@@ -21,7 +21,7 @@ from torch import nn
 
 from . import _lib as L
 from . import functional as Fh
-from .hip_layers import Conv1d, GroupedPosConv1d, LinearCT, PolyphaseConv1d, StackedLinearCT, finalize as _finalize
+from .hip_layers import Conv1d, GroupedPosConv1d, LinearCT, PolyphaseConv1d, StackedLinearCT, entry as _entry, finalize as _finalize
 from .ttv_v1.transformer_mega import LayerNorm
 
 CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
@@ -158,6 +158,7 @@ class Wav2vec2(nn.Module):
         self.arena = _finalize(self, device, materialize)
         return self
 
+    @_entry
     @torch.no_grad()
     def forward(self, x):
         m = self.wav2vec2.wav2vec2

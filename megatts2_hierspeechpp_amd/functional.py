@@ -90,7 +90,7 @@ def layernorm_mod(x, eps: float, mask=None, shift=None, scale=None, gamma=None, 
 
 
 def mha(q, k, v, n_heads: int, qk_scale: float, mask_q=None, mask_k=None, rel_k=None, rel_v=None, window=0,
-        out=None):
+        out=None, mask_dense=None, force_stream=False):
     """q [B, H*D, Tq], k/v [B, H*D, Tk] (any batch / channel strides, unit time stride) -> [B, H*D, Tq].
     Strided views let a batch live side by side on the column axis of one [C, B*T] matrix
     (``x.view(C, B, T).permute(1, 0, 2)``), the layout of the PLM loop."""
@@ -109,6 +109,15 @@ def mha(q, k, v, n_heads: int, qk_scale: float, mask_q=None, mask_k=None, rel_k=
         a.mask_q, a.mask_k = L.fptr(_c(mask_q)), L.fptr(_c(mask_k))
     if rel_k is not None:
         a.rel_k, a.rel_v, a.window = L.fptr(_c(rel_k)), L.fptr(_c(rel_v)), window
+    if mask_dense is not None:
+        # the reference's general attn_mask [B, 1, Tq, Tk] / [B, Tq, Tk] (attentions.py:147-155): 0 -> -1e4
+        md = mask_dense.reshape(B, Tq, Tk)
+        if md.dtype != torch.float32:
+            md = md.to(torch.float32)            # a dtype cast of the caller's bool mask, no arithmetic
+        md = _c(md)
+        a.mask_dense, a.mask_dense_bs = L.fptr(md), md.stride(0)
+    if force_stream:                              # tests: the key-streaming kernels at any length (hsp.h)
+        a.window = -(a.window + 1)
     L.check(L.lib().hsp_mha_f32(C.byref(a), L.stream_ptr()), "hsp_mha_f32")
     return o
 

@@ -29,7 +29,7 @@ from . import activations
 from . import modules
 from .alias_free_torch import Activation1d
 from .commons import get_padding
-from .hip_layers import Conv1d, ConvTranspose1d, Linear, StackedLinearCT, finalize as _finalize
+from .hip_layers import Conv1d, ConvTranspose1d, Linear, StackedLinearCT, entry as _entry, finalize as _finalize
 from .styleencoder import StyleEncoder
 
 UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / analysis only
@@ -277,6 +277,7 @@ class Generator(nn.Module):
         self.downs = DBlock(c0 // 8, c0, 4)
         self.proj = Conv1d(c0 // 8, c0 // 2, 7, padding=3)
 
+    @_entry
     def forward(self, x, pitch, g=None):
         x = self.conv_pre(x, cbias=self.cond(g), res=self.downs(pitch))
         for i in range(self.num_upsamples):
@@ -370,6 +371,7 @@ class SynthesizerTrn(nn.Module):
         e, e_ = self.sn(z, g)
         return self.dec(z, e, g=g), e_
 
+    @_entry
     @torch.no_grad()
     def infer(self, x_mel, w2v, length, f0, noise: Optional[torch.Tensor] = None):
         """:635-651 -> (o [B,1,320T], e_ [B,1,4T]).  ``noise`` ([B,192,T]) replaces the
@@ -379,6 +381,7 @@ class SynthesizerTrn(nn.Module):
         z = self._latent(w2v, f0, x_mask, g, noise, 1.0)
         return self._decode(z, g)
 
+    @_entry
     @torch.no_grad()
     def voice_conversion(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333, uncond=False,
                          noise: Optional[torch.Tensor] = None):
@@ -391,6 +394,7 @@ class SynthesizerTrn(nn.Module):
         z = self._latent(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
         return self._decode(z, g)[0]
 
+    @_entry
     @torch.no_grad()
     def voice_conversion_noise_control(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333,
                                        uncond=False, denoise_ratio=0, noise: Optional[torch.Tensor] = None):

@@ -190,14 +190,75 @@ class WeightArena:
         return self.views[(id(owner), name)]
 
 
+# Bumped whenever a HipLayer's parameters move (``.cuda()`` / ``.to(device)``) or are reloaded
+# (``load_state_dict``): a top-level mirror compares its own stamp with this counter on every entry call -- one
+# integer compare on the hot path -- and only walks its layers when something changed anywhere (ensure_ready()).
+_EPOCH = 0
+
+
+def _bump_epoch():
+    global _EPOCH
+    _EPOCH += 1
+
+
 class HipLayer(nn.Module):
-    """Base of modules that own packed device state."""
+    """Base of modules that own packed device state.  ``_hsp_stale`` says the packed copy no longer matches the
+    parameters (never packed, parameters moved to another device, or reloaded)."""
+
+    _hsp_stale = True
 
     def hsp_requests(self) -> List[Tuple[str, int]]:
         return []
 
     def hsp_fill(self, arena: WeightArena, materialize: bool) -> None:
         pass
+
+    def _apply(self, fn, *args, **kw):
+        before = [(q.device, q.data_ptr()) for q in self._parameters.values() if q is not None]
+        r = super()._apply(fn, *args, **kw)
+        after = [(q.device, q.data_ptr()) for q in self._parameters.values() if q is not None]
+        if before != after:
+            self.__dict__["_hsp_stale"] = True
+            _bump_epoch()
+        return r
+
+    def _load_from_state_dict(self, *args, **kw):
+        r = super()._load_from_state_dict(*args, **kw)
+        self.__dict__["_hsp_stale"] = True
+        _bump_epoch()
+        return r
+
+
+def ensure_ready(model: nn.Module) -> None:
+    """Drop-in behaviour of the reference's call sites (``Model(...).cuda()``, ``load_state_dict``, ``.eval()``,
+    then inference methods: inference_plm.py:215-262): the first inference call after the parameters moved or
+    changed folds / packs the weights on the device the parameters live on.  An explicit ``finalize(device)`` stays
+    available (multi-GPU jobs lay the arena out without materialising it).  Raises on CPU: no CPU fallback."""
+    if model.__dict__.get("_hsp_epoch") == _EPOCH:
+        return
+    if any(m._hsp_stale for m in model.modules() if isinstance(m, HipLayer)):
+        p = next(model.parameters(), None)
+        dev = p.device if p is not None else torch.device("cpu")
+        if dev.type != "cuda":
+            raise L.HspError(f"{type(model).__name__}: parameters are on {dev}; move the model to a ROCm device "
+                             "(.cuda() / .to(device)) -- the product path has no CPU fallback")
+        fin = getattr(model, "finalize", None)
+        if fin is not None:
+            fin(dev)
+        else:
+            finalize(model, dev)
+    model.__dict__["_hsp_epoch"] = _EPOCH
+
+
+def entry(fn):
+    """Decorator of a mirror's public inference methods: pack the weights on first use (ensure_ready)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kw):
+        ensure_ready(self)
+        return fn(self, *args, **kw)
+    return wrapped
 
 
 def _gather(src: torch.Tensor, idx_map: np.ndarray, dst: torch.Tensor):
@@ -632,6 +693,8 @@ def finalize(model: nn.Module, device, materialize: bool = True) -> WeightArena:
         arena.allocate(device)
         for m in layers:
             m.hsp_fill(arena, materialize)
+            m.__dict__["_hsp_stale"] = False
         torch.cuda.current_stream().synchronize()
     model._hsp_arena = arena
+    model.__dict__["_hsp_epoch"] = _EPOCH
     return arena

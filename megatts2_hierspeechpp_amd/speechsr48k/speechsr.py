@@ -12,7 +12,7 @@ from .. import activations
 from .. import functional as Fh
 from ..alias_free_torch import Activation1d
 from ..hierspeechpp_speechsynthesizer import AMPBlock1, _amp_stage
-from ..hip_layers import Conv1d, finalize as _finalize
+from ..hip_layers import Conv1d, entry as _entry, finalize as _finalize
 
 AMPBlock0 = AMPBlock1  # identical forward (speechsr48k/speechsr.py:53-62 vs hierspeechpp_speechsynthesizer.py:377-386)
 
@@ -63,10 +63,12 @@ class SynthesizerTrn(nn.Module):
     def finalize(self, device, materialize: bool = True):
         return _finalize(self, device, materialize)
 
+    @_entry
     @torch.no_grad()
     def forward(self, x):
         return self.dec(x)
 
+    @_entry
     @torch.no_grad()
     def infer(self, x, max_len=None):
         return self.dec(x[:, :, :max_len])

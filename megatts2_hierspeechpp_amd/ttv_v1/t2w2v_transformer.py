@@ -9,7 +9,7 @@ from torch import nn
 from .. import _lib as L
 from .. import attentions
 from .. import functional as Fh
-from ..hip_layers import Conv1d, ConvTranspose1d, HipLayer, LinearCT, finalize as _finalize
+from ..hip_layers import Conv1d, ConvTranspose1d, HipLayer, LinearCT, entry as _entry, finalize as _finalize
 from ..styleencoder import StyleEncoder
 from . import modules
 from .Gaussian import GaussianUpsampling, RangePredictor
@@ -113,6 +113,7 @@ class Megatts2PLM1(nn.Module):
                                           L.stream_ptr()), "hsp_plm_embed_f32")
         return x
 
+    @_entry
     def step_logits(self, tc_latent, codes, n, out=None):
         """Logits of position n-1 given the first n columns of ``tc_latent`` [B, 256, T] and of
         ``codes`` [B, >= n] (go token first): one pass of the loop body (:710-716) -> [1, vq_bins, B]."""
@@ -125,6 +126,7 @@ class Megatts2PLM1(nn.Module):
             x = Fh.copy_strided(x[0][:, :B * n].reshape(self.d_model, B, n)[:, :, n - 1].unsqueeze(0))
         return self.predict_layer(x, out=out)
 
+    @_entry
     @torch.no_grad()
     def infer(self, tc_latent: torch.Tensor, return_logits: bool = False):
         """tc_latent (B, D, T) -> int64 codes (B, T)  [+ fp32 logits (B, T, vq_bins)]."""
@@ -323,11 +325,13 @@ class SynthesizerTrn(nn.Module):
         self.arena = _finalize(self, device, materialize)
         return self
 
+    @_entry
     @torch.no_grad()
     def inf_extract_tc_latent(self, x, x_lengths, y_mel, y_length, tone, language, mrte_mel=None, mrte_mel_lengths=None,
                               length_scale=1, dur=None):
         """(:937-982) ids/tone/language int64 [B, N], x_lengths [B], y_mel [B, 80, Tm], y_length [B] ->
-        x_frame [B, 256, T2], g [B, 256, 1], x_lengths (float, frames / 2) [B], x_mask fp32 [B, 1, T2].
+        x_frame [B, 256, T2], g [B, 256, 1], x_lengths (float, frames / 2) [B], x_mask BOOL [B, 1, T2] (the
+        reference's dtypes, :979-982; ``inf_plm_gen`` takes that mask or a float one).
         ``dur`` [B, N] (optional) overrides the predicted durations (BASELINE config 3 pins them)."""
         B, N = x.shape
         C = self.inter_channels
@@ -359,11 +363,14 @@ class SynthesizerTrn(nn.Module):
         len2 = torch.ceil(frame_lengths).to(torch.int64).to(x.device)
         mask2 = Fh.sequence_mask(len2, T2)
         x_frame = self.dur_downsample(x_frame[:, :, ::2], mask=mask2, mask_mode=L.MASK_POST)
-        return x_frame, g, frame_lengths.to(x.device), mask2
+        return x_frame, g, frame_lengths.to(x.device), mask2.to(torch.bool)   # a dtype cast, as the reference's (:982)
 
+    @_entry
     @torch.no_grad()
     def inf_plm_gen(self, x_frame, g, codes, x_lengths, x_mask):
-        """(:984-994) codes int64 [B, T2] (or the reference's [1, 1, T2]) -> w2v [B, 1024, T2], lf0 [B, 4 T2]."""
+        """(:984-994) codes int64 [B, T2] (or the reference's [1, 1, T2]) -> w2v [B, 1024, T2], lf0 [B, 4 T2].
+        ``x_mask`` (bool as returned by inf_extract_tc_latent, or float) is accepted for the reference's signature; the
+        masks used here are rebuilt from ``x_lengths`` by the mask kernel (same values: :975-982)."""
         T2 = x_frame.shape[2]
         q = self.quantizer.decode(codes)
         # x_frame + ssl_proj(quantized) [+ w2v_encoder.cond(g), fused]
@@ -376,6 +383,7 @@ class SynthesizerTrn(nn.Module):
         mask4 = Fh.sequence_mask(4 * len2, 4 * T2)
         return w2v_pred, Fh.mask_mul(lf0, mask4).squeeze(1)
 
+    @_entry
     @torch.no_grad()
     def infer(self, x, x_lengths, mel_spk, mel_spk_lengths, tone, language, dur=None, mrte_mel=None, mrte_mel_lengths=None,
               noise_scale=1, noise_scale_w=1, length_scale=1, denoise_ratio=0):

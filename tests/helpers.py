@@ -240,8 +240,10 @@ def build_module(meta):
     raise KeyError(kind)
 
 
-def run_hip(meta, arrays, device):
-    """Run a fixture through the HIP product path; returns a list of numpy outputs."""
+def run_hip(meta, arrays, device, drop_in=False):
+    """Run a fixture through the HIP product path; returns a list of numpy outputs.
+    ``drop_in``: the reference's own call sequence (inference_plm.py:215-262) -- ``Model(...).cuda()``,
+    ``load_state_dict``, ``.eval()``, inference call -- with no finalize() anywhere."""
     from megatts2_hierspeechpp_amd import functional as Fh
     from megatts2_hierspeechpp_amd.hip_layers import finalize
     mod = build_module(meta)
@@ -255,8 +257,13 @@ def run_hip(meta, arrays, device):
         for k, v in mod.state_dict().items():
             if k not in sd:
                 sd[k] = torch.from_numpy(synth.synth_tensor(pre + k, tuple(v.shape), meta["seed"]))
-    mod.load_state_dict(sd, strict=True)
-    finalize(mod, device)
+    if drop_in:
+        mod = mod.cuda(device)
+        mod.load_state_dict(sd, strict=True)
+        _ = mod.eval()
+    else:
+        mod.load_state_dict(sd, strict=True)
+        finalize(mod, device)
     d = lambda k: torch.from_numpy(arrays[k]).to(device)
     kind = meta["kind"]
     mask = None

@@ -51,6 +51,64 @@ def test_golden_through_the_fused_two_gemm_kernel(name, device, monkeypatch):
         _close(o, r, f"{name}[{i}] (fused)")
 
 
+@pytest.mark.parametrize("name", ["infer_config1", "vc_noise_control", "tts_e2e", "plm_t12", "speechsr48", "speechsr24_real",
+                                  "ttv_front_n12", "denoise_l8000", "w2v_hidden7_t25", "generator"])
+def test_drop_in_call_sequence(name, device):
+    """INTEGRATION.md's snippet with only the import line changed: ``Model(...).cuda()`` -> ``load_state_dict`` ->
+    ``.eval()`` -> inference method (inference_plm.py:215-219,231-240,259-262; inference_vc.py:185-191), no finalize()
+    anywhere -- the weights are folded and packed by the first inference call -- and the result meets the same
+    reference outputs as the explicitly finalised model."""
+    names = H.fixture_names()
+    if name not in names:
+        alt = [n for n in names if n.startswith(name.rsplit("_", 1)[0])]
+        if not alt:
+            pytest.skip(f"no fixture {name}")
+        name = alt[0]
+    meta, arrays = H.load_fixture(name)
+    outs = H.run_hip(meta, arrays, device, drop_in=True)
+    for i, (o, r) in enumerate(zip(outs, H.outputs(arrays))):
+        _close(o, r, f"{name}[{i}] (drop-in)")
+
+
+def test_drop_in_tracks_reloaded_and_moved_weights(device):
+    """load_state_dict after the first call, and .to(device) / .cuda() again, are picked up by the next call; moving
+    to the CPU makes the next call refuse (no CPU fallback)."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import hip_layers
+    torch.manual_seed(0)
+    conv = hip_layers.Conv1d(16, 32, 3, padding=1)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = conv
+
+        @hip_layers.entry
+        def forward(self, x):
+            return self.c(x)
+
+    net = Net().cuda(device).eval()
+    x = torch.randn(2, 16, 40, device=device)
+    w1 = torch.randn(32, 16, 3)
+    net.load_state_dict({"c.weight": w1, "c.bias": torch.zeros(32)})
+    y1 = net(x)
+    _close(y1.cpu().numpy(), torch.nn.functional.conv1d(x.cpu(), w1, padding=1).numpy(), "first load")
+    arena1 = net._hsp_arena
+    assert net(x) is not None and net._hsp_arena is arena1          # nothing changed: no re-pack
+    net.load_state_dict({"c.weight": 2.0 * w1, "c.bias": torch.ones(32)})
+    _close(net(x).cpu().numpy(), (2.0 * torch.nn.functional.conv1d(x.cpu(), w1, padding=1) + 1.0).numpy(), "reload")
+    assert net._hsp_arena is not arena1
+    arena2 = net._hsp_arena
+    net.to(device)                                                   # already there: parameters do not move
+    net(x)
+    assert net._hsp_arena is arena2
+    net.cpu()
+    with pytest.raises(L.HspError):
+        net(x)
+    net.cuda(device)
+    _close(net(x).cpu().numpy(), (2.0 * torch.nn.functional.conv1d(x.cpu(), w1, padding=1) + 1.0).numpy(), "back on the GPU")
+
+
 @pytest.mark.parametrize("name", ["wn_h192", "dit_block", "convtr_k11_s5", "generator", "infer_ragged"])
 def test_survey_abi_names_give_identical_results(name, device):
     """The dispatching entry points named in SURVEY.md §8(b) (hsp_conv1d_f32, hsp_convtr1d_f32, hsp_wn_layer_f32,
@@ -420,6 +478,128 @@ def test_attention_strided_layout_matches_contiguous(device):
     w = torch.softmax(torch.einsum("bhdi,bhdj->bhij", qh, kh) * D ** -0.5, -1)
     want = torch.einsum("bhij,bhdj->bhdi", w, vh).reshape(B, H * D, T)
     _close(ref.cpu().numpy(), want.numpy(), "mha D=69")
+
+
+def _torch_attention(q, k, v, H, scale, mask=None, rel_k=None, rel_v=None, window=0):
+    """softmax attention written out with torch CPU ops: masked_fill(-1e4) and the relative-position terms of
+    attentions.py:157-188 (E[j - i + w] for |j - i| <= w), float64 accumulation for the long rows."""
+    B, HD, Tq = q.shape
+    Tk, D = k.shape[2], HD // H
+    qh, kh, vh = (t.double().view(B, H, D, -1) for t in (q, k, v))
+    s = torch.einsum("bhdi,bhdj->bhij", qh * scale, kh)
+    if window:
+        rel = torch.arange(Tk)[None, :] - torch.arange(Tq)[:, None]
+        inside = (rel.abs() <= window).double()
+        idx = (rel + window).clamp(0, 2 * window)
+        # only the band is non-zero: gather the 2w + 1 products per query instead of a [Tq, Tk, D] tensor
+        qe = torch.einsum("bhdi,rd->bhir", qh * scale, rel_k.double())            # [B, H, Tq, 2w+1]
+        s = s + torch.gather(qe, 3, idx[None, None].expand(B, H, Tq, Tk)) * inside
+    if mask is not None:
+        s = s.masked_fill(mask == 0, -1e4)
+    p = torch.softmax(s, -1)
+    o = torch.einsum("bhij,bhdj->bhdi", p, vh)
+    if window:
+        pw = torch.zeros(B, H, Tq, 2 * window + 1, dtype=torch.float64)
+        pw.scatter_add_(3, idx[None, None].expand(B, H, Tq, Tk), p * inside)
+        o = o + torch.einsum("bhir,rd->bhdi", pw, rel_v.double())
+    return o.reshape(B, HD, Tq).float()
+
+
+@pytest.mark.parametrize("B,H,D,Tq,Tk,window,masked", [
+    (1, 4, 16, 3200, 3200, 0, False),    # the denoiser's time conformer on a 20-s prompt (160 frames / s)
+    (2, 2, 96, 3000, 3000, 0, True),     # StyleEncoder self-attention on a minute of mel frames, ragged batch
+    (2, 4, 69, 45, 45, 0, False),        # PLM head dim, one key block
+    (1, 4, 64, 77, 333, 0, True),        # cross-attention shape (MRTE), Tq != Tk
+    (2, 4, 64, 2600, 2600, 4, True),     # text / mel encoders (window 4) beyond the whole-row kernel's LDS
+    (1, 4, 20, 700, 700, 4, False),      # MelEncoder head dim 20
+    (1, 1, 160, 300, 300, 4, True),      # head dim beyond 128: the second accumulator set of the window kernel
+])
+def test_attention_key_streaming_kernels(B, H, D, Tq, Tk, window, masked, device):
+    """The online-softmax kernels (no Tk ceiling) against torch, forced at every length, and -- where the whole-row
+    kernels still fit -- against those."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    g = torch.Generator().manual_seed(B * 1000 + D + Tk)
+    q = torch.randn(B, H * D, Tq, generator=g)
+    k, v = torch.randn(B, H * D, Tk, generator=g), torch.randn(B, H * D, Tk, generator=g)
+    rel_k = rel_v = None
+    if window:
+        rel_k, rel_v = 0.3 * torch.randn(2 * window + 1, D, generator=g), 0.3 * torch.randn(2 * window + 1, D, generator=g)
+    mq = mk = am = None
+    if masked:
+        lq = torch.tensor([Tq - (7 * b) % max(Tq // 3, 1) for b in range(B)])
+        lk = torch.tensor([Tk - (11 * b + 5) % max(Tk // 3, 1) for b in range(B)]) if Tk != Tq else lq
+        mq = (torch.arange(Tq)[None] < lq[:, None]).float().unsqueeze(1)
+        mk = (torch.arange(Tk)[None] < lk[:, None]).float().unsqueeze(1)
+        am = mq.unsqueeze(-1) * mk.unsqueeze(2)                                  # [B, 1, Tq, Tk]
+    scale = D ** -0.5
+    want = _torch_attention(q, k, v, H, scale, am, rel_k, rel_v, window)
+    dv = lambda t: None if t is None else t.to(device)
+    kw = dict(rel_k=dv(rel_k), rel_v=dv(rel_v), window=window)
+    got = Fh.mha(dv(q), dv(k), dv(v), H, scale, mask_q=dv(mq), mask_k=dv(mk), force_stream=True, **kw)
+    _close(got.cpu().numpy(), want.numpy(), "streaming, factor masks")
+    if masked:   # the reference's general attn_mask, float and bool
+        got = Fh.mha(dv(q), dv(k), dv(v), H, scale, mask_dense=dv(am), force_stream=True, **kw)
+        _close(got.cpu().numpy(), want.numpy(), "streaming, dense mask")
+    if Tk <= 1000:
+        got = Fh.mha(dv(q), dv(k), dv(v), H, scale, mask_q=dv(mq), mask_k=dv(mk), **kw)
+        _close(got.cpu().numpy(), want.numpy(), "whole-row kernel")
+        if masked:
+            got = Fh.mha(dv(q), dv(k), dv(v), H, scale, mask_dense=dv(am.bool()), **kw)
+            _close(got.cpu().numpy(), want.numpy(), "whole-row kernel, dense bool mask")
+    else:        # the default dispatch must reach the streaming kernel by itself
+        got = Fh.mha(dv(q), dv(k), dv(v), H, scale, mask_q=dv(mq), mask_k=dv(mk), **kw)
+        _close(got.cpu().numpy(), want.numpy(), "default dispatch at a length beyond LDS")
+
+
+def test_long_prompts_have_no_attention_ceiling(device):
+    """A 60-s prompt mel through the StyleEncoder (3 000 frames, ragged pair) and the denoiser's conformer block with
+    3 200 frames on its attention axis (a 20-s prompt: denoiser/conformer.py:45-60 runs nn.MultiheadAttention along
+    dim 0) against the oracle: lengths at which the score rows no longer fit LDS (round 2 refused them)."""
+    from oracle import hsp_oracle as O
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    g = torch.Generator().manual_seed(11)
+    # StyleEncoder
+    meta, _ = H.load_fixture("style_encoder")
+    mod = H.build_module(meta)
+    mod.load_state_dict(H.synth_sd(meta), strict=True)
+    finalize(mod, device)
+    T = 3000
+    lens = torch.tensor([T, 2211])
+    mel = torch.randn(2, 80, T, generator=g)
+    mask_c = O.sequence_mask(lens, T).unsqueeze(1).float()
+    mel = mel * mask_c
+    got = mod(mel.to(device), Fh.sequence_mask(lens.to(device), T)).cpu().numpy()
+    ref = O.style_encoder(H.oracle_sd(meta), meta["prefix"], mel, mask_c).numpy()
+    _close(got, ref, "StyleEncoder, 60 s of mel frames")
+    # conformer block: [A = 3200 frames, N = 6, C = 64]
+    meta, _ = H.load_fixture("mp_conformer")
+    mod = H.build_module(meta)
+    mod.load_state_dict(H.synth_sd(meta), strict=True)
+    finalize(mod, device)
+    x = torch.randn(3200, 6, 64, generator=g)
+    got = mod(x.transpose(1, 2).contiguous().to(device)).transpose(1, 2).cpu().numpy()
+    ref = O.mp_conformer_block(H.oracle_sd(meta), meta["prefix"], x).numpy()
+    _close(got, ref, "conformer block, 3 200 frames on the attention axis")
+
+
+def test_reference_attn_mask_signature(device):
+    """attentions.MultiHeadAttention.forward(x, c, attn_mask) as the reference calls it (attentions.py:39,147-155;
+    styleencoder.py:71-73): the [B, 1, T, T] outer-product mask gives the golden rel_mha output."""
+    name = "rel_mha_t50"
+    if name not in H.fixture_names():
+        pytest.skip("no fixture")
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    meta, arrays = H.load_fixture(name)
+    mod = H.build_module(meta)
+    mod.load_state_dict(H.synth_sd(meta), strict=True)
+    finalize(mod, device)
+    x = torch.from_numpy(arrays["x"]).to(device)
+    m = Fh.sequence_mask(torch.from_numpy(arrays["lengths"]).to(device), x.shape[2])
+    attn_mask = m.unsqueeze(2) * m.unsqueeze(-1)
+    _close(mod(x, x, attn_mask).cpu().numpy(), H.outputs(arrays)[0], "float attn_mask")
+    _close(mod(x, x, attn_mask.bool()).cpu().numpy(), H.outputs(arrays)[0], "bool attn_mask")
 
 
 def test_lstm_matches_torch_packed(device):
