@@ -16,7 +16,8 @@ resident in HBM; weights are the synthetic recipe (no checkpoints exist offline)
 every other rank only lays the arena out and receives the bytes by ONE chunked RCCL broadcast.
 
 Printed JSON (one line, rank 0): metric/value per the driver contract plus
-  broadcast_ms, rank_ms_per_step {min, max}, rccl_world -- the multi-GPU side
+  pack_ms (rank 0: fold + pack + upload of the weight arena), broadcast_ms (the dist.broadcast loop alone,
+  barrier-bracketed; null at N = 1), broadcast_gbs, rank_ms_per_step {min, max}, rccl_world -- the multi-GPU side
   event_median_ms -- median of the K steps, each bracketed by a HIP-event pair (SURVEY.md 8d protocol)
   roofline      -- dominant kernel (conv1d_mfma_kernel): algorithmic FLOP of all its launches in one step /
                    their summed duration, timed live with events on the launch stream, against the
@@ -176,10 +177,13 @@ def run_bench(args, make_workload, backend="nccl", device=None):
     sync()
     if world > 1:
         dist.barrier()
-    t0 = time.perf_counter()
-    arena = parallel.finalize_distributed(wl.model, dev, src=0)
+    tm = {}
+    arena = parallel.finalize_distributed(wl.model, dev, src=0, timings=tm)
     sync()
-    broadcast_ms = parallel.barrier_max(1e3 * (time.perf_counter() - t0), dev)
+    # pack_ms: rank 0's fold + pack + upload (the other ranks only lay the arena out); broadcast_ms: the
+    # dist.broadcast loop alone, max over ranks, None when no collective ran (world size 1)
+    pack_ms = parallel.gather_floats(tm["pack_ms"], dev)[0]
+    broadcast_ms = parallel.barrier_max(tm["broadcast_ms"], dev) if tm["broadcast_ms"] is not None else None
 
     lo, hi = parallel.shard_range(args.batch * world, rank, world)
     wl.prepare(lo, hi)
@@ -223,7 +227,9 @@ def run_bench(args, make_workload, backend="nccl", device=None):
             "rtf": (elapsed / args.steps) / audio_s_per_step, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
-            "broadcast_ms": broadcast_ms, "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)},
+            "pack_ms": pack_ms, "broadcast_ms": broadcast_ms,
+            "broadcast_gbs": (arena.buffer.numel() * 4 / 1e9) / (broadcast_ms * 1e-3) if broadcast_ms else None,
+            "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)},
             "rccl_world": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend if world > 1 else None,
         }
         if events:
@@ -340,6 +346,12 @@ def vocoder_roofline(args, wl, result):
         }
 
 
+def _progress(msg):
+    """stderr only (stdout carries the one JSON line): a long default run keeps saying what it is doing"""
+    sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] {msg}\n")
+    sys.stderr.flush()
+
+
 # ------------------------------------------------------------------------ CPU baseline
 def _cpu_model_string():
     try:
@@ -386,20 +398,37 @@ def cpu_baseline(args, wl, result):
         tt, ci1, ro1 = cpu_run(1, 50)
         t1.append(tt)
     m1 = float(np.median(t1))
-    # configs[1] sample: 8 x 4 s if it fits ~25 s of CPU work, else 1 x 4 s
+    # configs[1] sample: 8 x 4 s if one run fits ~25 s of CPU work, else 1 x 4 s; median of three runs
     est8 = m1 * 4 * 8
     sb = 8 if est8 < 25.0 else 1
-    t8, ci8, ro8 = cpu_run(sb, wl.frames)
+    t8s = []
+    for i in range(3):
+        _progress(f"cpu_baseline: {sb} x {wl.frames / 50:g} s, run {i + 1} of 3")
+        tt, ci8, ro8 = cpu_run(sb, wl.frames)
+        t8s.append(tt)
+    t8 = float(np.median(t8s))
+    # a like-for-like pair that shows the thread cap instead of asserting it (SURVEY.md 8d names os.cpu_count()):
+    # 2 x 4 s at the capped count and with every hardware thread (one run each; 256 threads oversubscribe oneDNN)
+    _progress("cpu_baseline: thread-cap pair")
+    t_cap, _, _ = cpu_run(min(2, sb), wl.frames)
+    torch.set_num_threads(host_cpus)
+    t_all, _, _ = cpu_run(min(2, sb), wl.frames)
+    torch.set_num_threads(cores)
     result["cpu_baseline"] = {
-        "value": sb * 320 * wl.frames / t8, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": sb * 320 * wl.frames / t8, "unit": "samples/s", "cores": cores, "kind": "port",
         "sample": f"oracle synth_infer on {sb} x {wl.frames / 50:g} s of configs[1]'s 32 x {wl.frames / 50:g} s "
-                  f"(one run, {t8:.2f} s)", "rtf": t8 / (sb * wl.frames / 50),
+                  f"(median of 3 runs: {', '.join(f'{t:.2f}' for t in t8s)} s)", "rtf": t8 / (sb * wl.frames / 50),
+        "all_threads": {"cores": host_cpus, "value": min(2, sb) * 320 * wl.frames / t_all, "unit": "samples/s",
+                        "same_sample_at_capped_threads": min(2, sb) * 320 * wl.frames / t_cap,
+                        "sample": f"{min(2, sb)} x {wl.frames / 50:g} s, one run each: {t_all:.2f} s with "
+                                  f"torch.set_num_threads({host_cpus}), {t_cap:.2f} s with {cores}"},
         "gpu_vs_oracle_maxabs": gpu_err(ci8, ro8),
         "config0_1x1s": {"value": 320 * 50 / m1, "unit": "samples/s", "rtf": m1 / 1.0,
                          "sample": f"1 utterance x 1 s, median of 3 runs ({m1:.3f} s)",
                          "gpu_vs_oracle_maxabs": gpu_err(ci1, ro1)},
         "host_cpus": host_cpus, "cpu_model": _cpu_model_string(),
-        "threads_note": "torch intra-op threads = min(host CPUs, 32): the oneDNN convs do not scale past that",
+        "threads_note": "headline value at torch intra-op threads = min(host CPUs, 32); `all_threads` is the same sample "
+                        "with every hardware thread",
     }
 
 
@@ -413,16 +442,21 @@ def main(argv=None):
     result, wl = run_bench(args, VocoderWorkload)
     import torch.distributed as dist
     if result is not None:
+        _progress(f"timed region done: {result['ms_per_step']:.2f} ms per step")
         if not args.no_roofline:
             vocoder_roofline(args, wl, result)
+            _progress(f"roofline pass done: frac {result['roofline']['frac']:.3f}")
         if result["n_gpus"] == 1 and not args.no_cpu_baseline:
             cpu_baseline(args, wl, result)
         if result["n_gpus"] == 1 and not args.no_extra:
             from tools import bench_extra
             extra = {}
+            _progress("extra_configs: vocoder 1 x 1 s")
             extra["vocoder_b1_1s"] = bench_extra.vocoder_b1_1s(wl.dev, steps=20, net=wl.model)
+            _progress("extra_configs: vocoder + SpeechSR48, batch 32")
             extra["sr48_b32"] = bench_extra.sr48_b32(wl.dev, steps=5, net=wl.model)
             del wl
+            _progress("extra_configs: full TTS, batch 16")
             extra["tts_b16"] = bench_extra.tts_b16(torch_device(), steps=3)
             result["extra_configs"] = extra
         print(json.dumps(result), flush=True)

@@ -56,8 +56,10 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   int epi = select_epilogue(a);
   if (act && epi != HSP_EPI_INIT) epi = HSP_EPI_GEN;  // the activation shapes carry INIT and GEN only
   // the window pitch is a compile-time constant of the shape (tile columns + 64): halos beyond 61 columns
-  // (the 64-tap blocks of the wav2vec2 positional conv) go to the one shape with a wider pitch
-  if ((a.K - 1) * a.dil + 3 > 64) return gated ? HSP_EINVAL : hsp_conv_tile_S64W(a, epi, act, s, plan_out);
+  // (the 64-tap blocks of the wav2vec2 positional conv; WN in-layers with dilation_rate > 1) go to the two
+  // shapes with a wider pitch (plain / gated rows; up to 125 columns, beyond: HSP_EINVAL from pick_lkc)
+  if ((a.K - 1) * a.dil + 3 > 64)
+    return gated ? hsp_conv_tile_S64GW(a, epi, act, s, plan_out) : hsp_conv_tile_S64W(a, epi, act, s, plan_out);
 #ifdef HSP_TUNING
   // force a tile shape (results stay right)
   if (!gated && a.debug & 256) return hsp_conv_tile_M128(a, epi, act, s, plan_out);

@@ -994,12 +994,13 @@ using S64 = Cfg<2, 2, 1, 1, 4, 2>;     //  64 x 64   short sequences: many small
 using S64G = Cfg<1, 4, 2, 1, 4, 2>;    //  64 x 128  short sequences, gated rows (needs TM even)
 using S32 = Cfg<1, 4, 1, 1, 4, 2>;     //  32 x 128
 using S64W = Cfg<2, 2, 1, 1, 4, 2, 128>;   //  64 x 64 with a 192-float window pitch: halos of 62 ... 125 columns
+using S64GW = Cfg<1, 4, 2, 1, 4, 2, 128>;  //  64 x 128 gated rows with a 256-float pitch (WN with dilation_rate > 1)
 
 }  // namespace hspconv
 
 // One function per tile shape (hsp_conv1d_tile.hip, compiled once per shape): launches the instantiation
 // for (epi, act) or returns HSP_EINVAL when the shape does not carry that combination.
-#define HSP_TILE_LIST(X) X(M128) X(M64) X(M32) X(M64P) X(M32P) X(S64) X(S64G) X(S32) X(S64W)
+#define HSP_TILE_LIST(X) X(M128) X(M64) X(M32) X(M64P) X(M32P) X(S64) X(S64G) X(S32) X(S64W) X(S64GW)
 #define HSP_TILE_DECL(name) \
   int hsp_conv_tile_##name(const hsp_conv1d_args& a, int epi, bool act, hipStream_t s, int32_t* plan_out);
 HSP_TILE_LIST(HSP_TILE_DECL)

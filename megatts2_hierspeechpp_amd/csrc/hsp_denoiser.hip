@@ -7,12 +7,15 @@
 
 namespace {
 
+// one thread per element, no grid-stride loop in these kernels: the grid covers every element (the x dimension
+// of a grid holds 2^31 - 1 blocks) or the launcher refuses (dn_fits)
+constexpr int64_t DN_MAX_BLOCKS = 0x7fffffff;
 inline unsigned dn_grid(int64_t n, int threads) {
   int64_t b = (n + threads - 1) / threads;
   if (b < 1) b = 1;
-  if (b > 1048576) b = 1048576;
-  return (unsigned)b;
+  return (unsigned)(b > DN_MAX_BLOCKS ? DN_MAX_BLOCKS : b);
 }
+inline bool dn_fits(int64_t n, int threads) { return (n + threads - 1) / threads <= DN_MAX_BLOCKS; }
 
 // block-wide sum of a double (1024 threads at most); every thread receives the total
 __device__ __forceinline__ double dn_block_sum(double v, double* sh) {
@@ -160,6 +163,7 @@ extern "C" int hsp_mag_pha_f32(const float* spec, int64_t s_ld, float* mag, floa
                                float compress, void* stream) {
   if (!spec || !mag || !pha || n_freqs < 2 || T <= 0 || s_ld < T) return HSP_EINVAL;
   const int64_t total = (int64_t)n_freqs * T;
+  if (!dn_fits(total, 256)) return HSP_EINVAL;
   hipLaunchKernelGGL(mag_pha_kernel, dim3(dn_grid(total, 256)), dim3(256), 0, HSP_STREAM, spec, s_ld, mag, pha, n_freqs, T,
                      compress);
   return (int)hipGetLastError();
@@ -178,6 +182,7 @@ extern "C" int hsp_dwconv_bn_silu_f32(const float* x, const float* w, const floa
   if (!x || !w || !bias || !bn_weight || !bn_bias || !bn_mean || !bn_var || !y) return HSP_EINVAL;
   if (B <= 0 || C <= 0 || N <= 0 || K <= 0 || (K & 1) == 0) return HSP_EINVAL;
   const int64_t total = (int64_t)B * C * N;
+  if (!dn_fits(total, 256)) return HSP_EINVAL;
   hipLaunchKernelGGL(dwconv_bn_silu_kernel, dim3(dn_grid(total, 256)), dim3(256), 0, HSP_STREAM, x, w, bias, bn_weight, bn_bias,
                      bn_mean, bn_var, bn_eps, y, C, N, K, total);
   return (int)hipGetLastError();
@@ -187,12 +192,14 @@ extern "C" int hsp_lsigmoid_mul_f32(const float* m, const float* slope, float be
                                     int32_t F, void* stream) {
   if (!m || !slope || !mag || !out || T <= 0 || F <= 0) return HSP_EINVAL;
   const int64_t total = (int64_t)T * F;
+  if (!dn_fits(total, 256)) return HSP_EINVAL;
   hipLaunchKernelGGL(lsigmoid_mul_kernel, dim3(dn_grid(total, 256)), dim3(256), 0, HSP_STREAM, m, slope, beta, mag, out, F, total);
   return (int)hipGetLastError();
 }
 
 extern "C" int hsp_atan2_f32(const float* y, const float* x, float* out, int64_t n, void* stream) {
   if (!y || !x || !out || n <= 0) return HSP_EINVAL;
+  if (!dn_fits(n, 256)) return HSP_EINVAL;
   hipLaunchKernelGGL(atan2_kernel, dim3(dn_grid(n, 256)), dim3(256), 0, HSP_STREAM, y, x, out, n);
   return (int)hipGetLastError();
 }
@@ -201,6 +208,7 @@ extern "C" int hsp_polar_f32(const float* mag, const float* pha, float power, fl
                              int64_t im_ld, int32_t F, int32_t T, void* stream) {
   if (!mag || !pha || !re || !im || F <= 0 || T <= 0 || re_ld < T || im_ld < T) return HSP_EINVAL;
   const int64_t total = (int64_t)F * T;
+  if (!dn_fits(total, 256)) return HSP_EINVAL;
   hipLaunchKernelGGL(polar_kernel, dim3(dn_grid(total, 256)), dim3(256), 0, HSP_STREAM, mag, pha, power, re, re_ld, im, im_ld, T,
                      total);
   return (int)hipGetLastError();
@@ -210,6 +218,7 @@ extern "C" int hsp_istft_ola_f32(const float* frames, int64_t f_ld, const float*
                                  int32_t hop, int32_t T, float scale, void* stream) {
   if (!frames || !window || !out || n_fft <= 0 || (n_fft & 1) || hop <= 0 || hop > n_fft || T < 2 || f_ld < T) return HSP_EINVAL;
   const int64_t L = (int64_t)hop * (T - 1);
+  if (!dn_fits(L, 256)) return HSP_EINVAL;
   hipLaunchKernelGGL(istft_ola_kernel, dim3(dn_grid(L, 256)), dim3(256), 0, HSP_STREAM, frames, f_ld, window, out, n_fft, hop, T,
                      L, scale);
   return (int)hipGetLastError();

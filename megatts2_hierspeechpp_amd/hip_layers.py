@@ -85,12 +85,14 @@ def launch_group(kind: str, fn, structs, *extra):
     hook(kind, flops, nbytes, e0, e1, structs[0][0])
 
 
-def _launch(kind: str, fn, a, flops: int, nbytes: int, soft: bool = False):
+def _launch(kind: str, fn, a, flops: int, nbytes: int, soft: bool = False, keep=()):
     """``soft``: return the status instead of raising on HSP_EINVAL (a shape the requested fusion does not
     cover; the caller then issues the un-fused launches)."""
     a.debug = DEBUG_FLAGS
     if _DEFER is not None:
-        _DEFER.append((a, flops, nbytes))
+        # the struct holds raw device pointers: `keep` pins the tensors behind them until launch_group() has run
+        assert not soft and not a.ln_c1 and not a.split_row, "deferred(): no soft / fused-LayerNorm / split launches"
+        _DEFER.append((a, flops, nbytes, keep))
         return 0
     if SURVEY_ABI:
         fn = L.lib().hsp_convtr1d_f32 if a.rows == L.ROWS_SHUFFLE else L.lib().hsp_conv1d_f32
@@ -446,7 +448,8 @@ class Conv1d(_ConvBase):
                 a.ln_c1 = None
                 _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
         else:
-            _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes)
+            _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes,
+                    keep=(x, out, res, cbias, mask, cscale))
         return out
 
 

@@ -58,9 +58,11 @@ class LayerNorm(HipLayer):
 
 
 class WN(nn.Module):
-    """modules.WN (modules.py:111-176).  Per layer: one gated in-conv launch (conv k +
-    conditioning bias + tanh*sigmoid in the epilogue) and two 1x1 launches over the row
-    halves of res_skip (residual update of x, accumulation of the skip output)."""
+    """modules.WN (modules.py:111-176).  Per layer either ONE launch (hsp_wn_layer_f32 -> csrc/hsp_gemm2.hip: gated
+    conv, tanh * sigmoid and the res / skip 1x1 with the activations on chip) when the launch has at least
+    FUSE_MIN_TILES column tiles, or two: the gated in-conv (conv k + conditioning bias + tanh * sigmoid in the
+    epilogue) and one token-GEMM launch writing both row halves of res_skip (residual update of x, accumulation of
+    the skip output; hsp_conv1d_args.split_row)."""
 
     def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
         super().__init__()
@@ -74,6 +76,9 @@ class WN(nn.Module):
             self.cond_layer = Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1, weight_norm=True)
         for i in range(n_layers):
             d = dilation_rate ** i
+            if (kernel_size - 1) * d + 3 > 128:
+                raise L.HspError(f"WN layer {i}: halo (k - 1) * dilation + 3 = {(kernel_size - 1) * d + 3} columns exceeds "
+                                 "the widest window pitch of the gated conv kernel (128)")
             self.in_layers.append(Conv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=d,
                                          padding=int((kernel_size * d - d) / 2), weight_norm=True,
                                          rows=L.ROWS_GATE_WN))
@@ -93,6 +98,19 @@ class WN(nn.Module):
         for i in range(self.n_layers):
             cb = gc[:, 2 * H * i: 2 * H * (i + 1)] if gc is not None else None
             last = i == self.n_layers - 1
+            if not fuse and not last and H % 64 == 0:
+                # layer by layer: gated conv, then BOTH halves of res_skip in one token-GEMM launch
+                # (hsp_conv1d_args.split_row; None = the library has no such kernel for this shape)
+                self.in_layers[i](x, cbias=cb, out=acts)
+                both = self.res_skip_layers[i](acts, res=x, mask=x_mask, mask_mode=L.MASK_POST,
+                                               split_out=(H, out, out is not None))
+                if both is not None:
+                    x, out = both
+                    continue
+                x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
+                out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
+                x = x_new
+                continue
             with (hip_layers.deferred() if fuse else contextlib.nullcontext()) as args:
                 self.in_layers[i](x, cbias=cb, out=acts)
                 if not last:

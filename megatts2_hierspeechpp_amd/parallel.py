@@ -52,16 +52,39 @@ def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 2
     return buf
 
 
-def finalize_distributed(model, device, src: int = 0):
+def finalize_distributed(model, device, src: int = 0, timings: dict = None):
     """Rank ``src`` folds + packs the weights; every other rank only lays the arena out
-    (identical offsets by construction) and receives the bytes by broadcast."""
+    (identical offsets by construction) and receives the bytes by broadcast.
+
+    ``timings`` (optional dict) receives ``pack_ms`` -- this rank's fold + pack + upload (or arena layout) -- and
+    ``broadcast_ms`` -- the ``dist.broadcast`` loop alone, bracketed by a barrier and device synchronisation on both
+    sides so that it starts when the slowest rank is ready and ends when the last byte has landed; ``None`` at
+    world size 1 (no collective runs)."""
+    import time
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    on_gpu = torch.device(device).type == "cuda"
+    sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)
     rank = dist.get_rank() if dist.is_initialized() else 0
+    sync()
+    t0 = time.perf_counter()
     res = model.finalize(device, materialize=(rank == src))
+    sync()
+    pack_ms = 1e3 * (time.perf_counter() - t0)
     # hip_layers.finalize leaves the arena on the model whatever the model's own finalize() returns (some return self)
     arena = getattr(model, "_hsp_arena", None)
     if arena is None:
         arena = res
-    broadcast_buffer(arena.buffer, src)
+    bc_ms = None
+    if multi:
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        broadcast_buffer(arena.buffer, src)
+        sync()
+        dist.barrier()
+        bc_ms = 1e3 * (time.perf_counter() - t0)
+    if timings is not None:
+        timings["pack_ms"], timings["broadcast_ms"] = pack_ms, bc_ms
     return arena
 
 

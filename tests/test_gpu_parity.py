@@ -298,6 +298,35 @@ def test_wn_and_attention_longer_ragged(device):
     _close(got, ref, "dit T=333")
 
 
+def test_wn_with_dilation_rate_2_vs_oracle(device):
+    """modules.WN(dilation_rate = 2, 5 layers): dilations 1 ... 16, the last in-layer's halo (67 columns) takes the
+    wide-pitch gated tile shape; both launch policies (layer by layer / the fused entry point's own fallback)."""
+    from oracle import hsp_oracle as O
+    from megatts2_hierspeechpp_amd import functional as Fh
+    from megatts2_hierspeechpp_amd import modules
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    from megatts2_hierspeechpp_amd import synth
+    wn = modules.WN(192, 5, 2, 5, gin_channels=256)
+    sd = {k: torch.from_numpy(synth.synth_tensor("w." + k, tuple(v.shape), 21)) for k, v in wn.state_dict().items()}
+    wn.load_state_dict(sd)
+    finalize(wn, device)
+    T = 150
+    lens = np.array([150, 97], np.int64)
+    rng = np.random.default_rng(4)
+    mask_c = O.sequence_mask(torch.from_numpy(lens), T).unsqueeze(1).float()
+    x = torch.from_numpy(rng.standard_normal((2, 192, T)).astype(np.float32)) * mask_c
+    g = torch.from_numpy(rng.standard_normal((2, 256, 1)).astype(np.float32))
+    ref = O.wavenet({"w." + k: v for k, v in sd.items()}, "w", x, mask_c, g, 192, 5, 5, dilation_rate=2).numpy()
+    mask = Fh.sequence_mask(torch.from_numpy(lens).to(device), T)
+    for fuse_min in (1 << 30, 0):
+        modules.FUSE_MIN_TILES, saved = fuse_min, modules.FUSE_MIN_TILES
+        try:
+            got = wn(x.to(device), mask, g=g.to(device)).cpu().numpy()
+        finally:
+            modules.FUSE_MIN_TILES = saved
+        _close(got, ref, f"WN dilation_rate 2 (FUSE_MIN_TILES {fuse_min})")
+
+
 def test_linear_interp_long_sequence_matches_torch_cpu(device):
     """SpeechSR's x3 linear interpolation at the full 4-s length: torch-CPU evaluates the source
     index with a single-rounding fp32 FMA; mul+sub is off by 2e-3 on white noise at L = 64000

@@ -264,6 +264,28 @@ def test_conv_dispatch_covers_every_host_side_combination():
     assert {(128, 128), (64, 256), (32, 512), (64, 64), (64, 128), (32, 128)} <= seen, seen
 
 
+def test_wide_halo_convs_have_a_tile_shape_plain_and_gated():
+    """Halos beyond the 64-column window slack: the 64-tap blocks of the wav2vec2 positional conv (plain rows) and WN
+    in-layers with dilation_rate > 1 (gated rows: k = 5, dilation 16 and 25 -- modules.WN accepts any dilation_rate, as
+    the reference does) both find a shape; past the widest pitch the library refuses and modules.WN says so at
+    construction."""
+    from megatts2_hierspeechpp_amd import _lib as L_
+    from megatts2_hierspeechpp_amd import modules
+    lib = L_.lib()
+    plan = (ctypes.c_int32 * 4)()
+    for B, L in ((1, 50), (32, 200), (32, 4000)):
+        for kw in (dict(rows=L_.ROWS_GATE_WN), dict(rows=L_.ROWS_GATE_GLU, mask=True, res=True), dict(res=True)):
+            for K, dil in ((5, 16), (5, 25), (64, 1), (3, 60)):
+                a = _plan_args(B, 192, L, K, 192, dil=dil, **kw)
+                assert lib.hsp_conv1d_mfma_plan(ctypes.byref(a), ctypes.byref(plan)) == 0, (B, L, K, dil, kw)
+                assert (plan[0], plan[1]) == ((64, 128) if "rows" in kw else (64, 64))
+        a = _plan_args(B, 192, L, 5, 192, dil=32, rows=L_.ROWS_GATE_WN)      # halo 131 > 125
+        assert lib.hsp_conv1d_mfma_plan(ctypes.byref(a), ctypes.byref(plan)) == L_.EINVAL
+    modules.WN(192, 5, 2, 5, gin_channels=256)                               # dilations 1 ... 16
+    with pytest.raises(L_.HspError):
+        modules.WN(192, 5, 2, 6, gin_channels=256)                           # dilation 32
+
+
 def test_release_library_refuses_the_tuning_word():
     """hsp_conv1d_args.debug selects kernel tuning switches that exist only in libhsp_tune.so; the shipped
     library must reject any non-zero value instead of silently producing wrong audio."""
@@ -305,7 +327,7 @@ def test_vocoder_wn_layers_and_dit_ffn_take_the_one_launch_path(monkeypatch):
     monkeypatch.setattr(M.Fh, "mask_mul", lambda x, m: x)
     monkeypatch.setattr(M.Fh, "layernorm_mod", lambda x, *a, **k: torch.empty_like(x))
     monkeypatch.setattr(M.Fh, "mha", lambda q, k, v, *a, **kw: torch.empty_like(q))
-    monkeypatch.setattr(HL, "_launch", lambda kind, fn, a, fl, nb, soft=False: (HL._DEFER.append((a, fl, nb)) if HL._DEFER is not None else None) or 0)
+    monkeypatch.setattr(HL, "_launch", lambda kind, fn, a, fl, nb, soft=False, keep=(): (HL._DEFER.append((a, fl, nb, keep)) if HL._DEFER is not None else None) or 0)
     wn = M.WN(192, 5, 1, 3, gin_channels=0)
     blk = M.DiTConVBlock(192, 2, mlp_ratio=4.0, kernel=5)
     for m in list(wn.modules()) + list(blk.modules()):

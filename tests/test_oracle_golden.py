@@ -82,3 +82,28 @@ def test_mel_oracle_matches_float64_restatement(L, B):
     assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
     fbo = O.melscale_fbanks_htk(641, 0.0, 8000.0, 80, 16000).numpy()
     assert np.abs(fbo - fb).max() < 1e-4 and (fbo >= 0).all() and (fbo.sum(0) > 0).all()
+
+
+@pytest.mark.parametrize("L", [16000, 4801, 24000])
+def test_mel_oracle_matches_transformers_audio_utils(L):
+    """A third, independent implementation that IS in the image: HF ``transformers.audio_utils`` (the reference's own
+    dependency family; pure numpy).  ``spectrogram(power = 2, center, reflect, periodic Hann)`` with
+    ``mel_filter_bank(norm = None, mel_scale = "htk")`` is the same published algorithm torchaudio's MelSpectrogram
+    implements.  The prompt mel stays "parity unpinned" upstream (no torchaudio-produced vector exists anywhere), but
+    three implementations by three authors agreeing is the strongest statement this image allows."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import hsp_oracle as O
+    rng = np.random.default_rng(L + 1)
+    t = np.arange(L) / 16000.0
+    x = (0.1 * rng.standard_normal(L) + 0.3 * np.sin(2 * np.pi * 330.0 * t) * np.linspace(1, 0, L)).astype(np.float32)
+    fb = au.mel_filter_bank(num_frequency_bins=641, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0,
+                            sampling_rate=16000, norm=None, mel_scale="htk")
+    fbo = O.melscale_fbanks_htk(641, 0.0, 8000.0, 80, 16000).numpy()
+    assert fb.shape == fbo.shape and np.abs(fb - fbo).max() < 1e-4
+    win = au.window_function(1280, "hann", periodic=True)
+    mel = au.spectrogram(x.astype(np.float64), win, frame_length=1280, hop_length=320, fft_length=1280, power=2.0,
+                         center=True, pad_mode="reflect", onesided=True, mel_filters=fb, mel_floor=0.0, dtype=np.float64)
+    want = np.log(mel + 1e-3)[:, :-1]                                   # the wrapper's log(x + 0.001)[..., :-1]
+    got = O.mel_spectrogram_fixed(torch.from_numpy(x)[None]).numpy()[0]
+    assert got.shape == want.shape == (80, L // 320)
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())

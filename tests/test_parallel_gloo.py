@@ -134,6 +134,7 @@ def test_bench_control_flow_world2_cpu_stand_in():
     assert line["n_gpus"] == 2 and line["rccl_world"] == 2 and line["scaling"] == "weak"
     assert line["steps"] == 3 and line["warmup"] == 1 and line["config"]["shard_of_rank0"] == [0, 7]
     assert line["broadcast_ms"] > 0 and line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"]
+    assert line["pack_ms"] > 0 and line["broadcast_gbs"] > 0       # the collective alone, apart from the packing
     # whole-job value: the units ALL ranks processed over the max-over-ranks time
     assert abs(line["value"] - 14 * 1000 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
     json.dumps(line)
