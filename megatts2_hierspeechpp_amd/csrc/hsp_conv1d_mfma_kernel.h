@@ -380,107 +380,17 @@ struct Prod {
 // C/D map of the 32x32 MFMA forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #define HSP_ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
 
-template <class C, int EPI, bool ACT>
-__global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
-                                                                          const int n_nt, const int lkc,
-                                                                          const int xvec) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int BM = C::BM, BN = C::BN, TM = C::kTM, TN = C::kTN;
-  const LdsPlan P = make_plan<C>(a.K, a.dil, ACT ? HSP_PRO_ACT1D : HSP_PRO_NONE, lkc);
+// The consumer role of one wave: a (TM x TN) grid of 32 x 32 MFMA blocks at rows m0 + wm * TM * 32, columns
+// t0 + wn * TN * 32 of the tile.  TM / TN are the shape's own (C::kTM, C::kTN) except in a narrow tail tile
+// (has_tail_path): the slab and window layouts in LDS belong to the SHAPE (C::BM, C::XWP), only the part of the
+// tile a wave multiplies changes.
+template <class C, int EPI, bool ACT, int TM, int TN>
+__device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const LdsPlan& P, float* const lds, const int b,
+                                             const int m0, const int t0, const int p0, const int wm, const int wn,
+                                             const int lane, const int nchunks, const int lkc, const int xvec) {
+  constexpr int BM = C::BM;
   const int KC = P.kc;
-
-  // blockIdx.x = mt + n_mt * (nt + n_nt * b): row tiles fastest, so the blocks that
-  // round-robin onto one XCD keep hitting the same weight slab in that XCD's L2.
-  int bid = blockIdx.x;
-  const int mt = bid % n_mt;
-  bid /= n_mt;
-  const int nt = bid % n_nt;
-  const int b = bid / n_nt;
-  const int m0 = mt * BM, t0 = nt * BN;
-  const int p0 = t0 - a.pad;  // first activated-input position of the window
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int nchunks = (a.Cin + KC - 1) >> lkc;
-
-  if (wave >= C::NCW) {
-    // ------------------------------------------------------------ producers
-    const int pw = wave - C::NCW;
-    const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
-                      (int)a.x_ts, a.prologue, a.slope};
-    const float* xb = a.x + (int64_t)b * a.x_bs;
-    using PR = Prod<C>;
-    float* const Ws0 = lds;
-    float* const Xa0 = lds + P.xa_off;
-    if constexpr (!ACT) {
-      const int p0a = p0 & ~3;
-      const bool fast = xvec && m0 + BM <= a.M && (a.Cin & (KC - 1)) == 0 && !HSP_DBG(a, 512);  // wave-uniform
-      if (fast) {
-        const float* const wtile = a.w + m0;
-        const float* const xtile = xb + p0a;
-        const int xcs = (int)a.x_cs;
-        const unsigned wofs = 4u * (unsigned)((lane / PR::CPR) * a.w_ld + (lane % PR::CPR) * 4);
-        if (p0a < 0 || p0a + 4 * ((P.xw + 3 + 3) >> 2) > a.Lin) PR::zero_x_rows(P, Xa0, pw, lane);
-        PR::dma_w_fast(wtile, a.w_ld, a.Cin, a.K, P, Ws0, 0, pw, wofs);
-        PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0, 0, p0a, pw, lane);
-        wait_vm0();
-        if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
-        HSP_BARRIER(a);
-        for (int c = 0; c < nchunks; ++c) {
-          const int nb = (c + 1) & 1;
-          if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
-            PR::dma_w_fast(wtile, a.w_ld, a.Cin, a.K, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, pw, wofs);
-            PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0a, pw, lane);
-            wait_vm0();
-            if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
-          }
-          HSP_BARRIER(a);
-        }
-        return;
-      }
-      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
-      if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
-      wait_vm0();
-      if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
-      HSP_BARRIER(a);
-      for (int c = 0; c < nchunks; ++c) {
-        const int nb = (c + 1) & 1;
-        if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
-          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
-          if (xvec) PR::dma_x16(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0a, pw, lane);
-          else PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
-          wait_vm0();
-          if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
-        }
-        HSP_BARRIER(a);
-      }
-    } else {
-      float* const scr = lds + P.scr_off + pw * P.scr_sz;   // raw[2][rpw][xrwp], a2[a2w]
-      float* const a2 = scr + 2 * P.rpw * P.xrwp;
-      const int rsz = P.rpw * P.xrwp;
-      PR::dma_raw(pa, P, scr, xb, 0, p0, pw, lane);
-      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
-      wait_vm0();
-      PR::act_rows(pa, P, scr, a2, Xa0, 0, p0, pw, lane);
-      if (nchunks > 1) PR::dma_raw(pa, P, scr + rsz, xb, KC, p0, pw, lane);
-      wait_vm0();
-      HSP_BARRIER(a);
-      for (int c = 0; c < nchunks; ++c) {
-        const int nb = (c + 1) & 1;
-        if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
-          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
-          if (c + 2 < nchunks) PR::dma_raw(pa, P, scr + (c & 1) * rsz, xb, (c + 2) << lkc, p0, pw, lane);
-          PR::act_rows(pa, P, scr + nb * rsz, a2, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0, pw, lane);
-          wait_vm0();
-        }
-        HSP_BARRIER(a);
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------- consumers
-  const int wm = wave / C::kWN, wn = wave % C::kWN;
+  const int wave = wm * C::kWN + wn;               // only the VEC epilogue's staging slot uses it (full tiles)
   const int l32 = lane & 31, half = lane >> 5;
   const int mw = m0 + wm * (TM * 32);               // first packed row of this wave
   const int tw = t0 + wn * (TN * 32) + l32;         // this lane's column in block n = 0
@@ -915,6 +825,157 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
   }
 }
 
+// does this instantiation carry the narrow-tail consumer (a last column tile with at most 32 valid columns is
+// computed as 4 waves x (32 rows x 32 columns) instead of 4 waves x (64 x 64): a quarter of the MFMAs)?
+template <class C, int EPI, bool ACT>
+constexpr bool has_tail_path() {
+  return EPI == HSP_EPI_INIT && !ACT && C::kWM * C::kWN == 4 && C::kTM * C::kWM == 4 && C::kTN * C::kWN == 4;  // 128 x 128
+}
+
+// `sched` = g | tail << 8 (host: launch_one).
+//   g = 0: blockIdx.x = mt + n_mt * ct, row tiles fastest: the blocks that round-robin onto one XCD keep hitting the
+//          same weight slab in that XCD's L2 -- but the input window of a column tile is then fetched once per row
+//          tile, by a different XCD each time.
+//   g > 0: XCD-grouped.  Blocks b and b + 8 share an XCD (observed dispatch order; speed only, never correctness).
+//          XCD x = blockIdx.x % 8 owns row group (x % (n_mt / g)) = g consecutive row tiles, whose weight slabs fit
+//          its L2 together, and walks its column tiles with those g row tiles adjacent in time: the window is
+//          fetched from HBM / Infinity Cache once per XCD group instead of once per row tile.
+//   tail:  the last column tile of every utterance holds <= 32 valid columns; those tiles are enumerated LAST
+//          (short jobs at the end of the grid) and take the narrow consumer.
+template <class C, int EPI, bool ACT>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const hsp_conv1d_args a, const int n_mt,
+                                                                          const int n_nt, const int lkc,
+                                                                          const int xvec, const int sched) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = C::BM, BN = C::BN, TM = C::kTM, TN = C::kTN;
+  const LdsPlan P = make_plan<C>(a.K, a.dil, ACT ? HSP_PRO_ACT1D : HSP_PRO_NONE, lkc);
+  const int KC = P.kc;
+
+  int mt, ct;
+  {
+    const int g = sched & 255;
+    const int bid = blockIdx.x;
+    if (g == 0) {
+      mt = bid % n_mt;
+      ct = bid / n_mt;
+    } else {
+      const int x = bid & 7, q = bid >> 3;
+      const int groups_m = n_mt / g, nx = 8 / groups_m;
+      mt = (x % groups_m) * g + q % g;
+      ct = (q / g) * nx + x / groups_m;
+      if (ct >= n_nt * a.B) return;  // grid padding (whole workgroup, before any barrier)
+    }
+  }
+  int nt, b;
+  bool tail_tile = false;
+  if (sched >> 8) {
+    const int n_main = (n_nt - 1) * a.B;
+    if (ct < n_main) {
+      nt = ct % (n_nt - 1);
+      b = ct / (n_nt - 1);
+    } else {
+      nt = n_nt - 1;
+      b = ct - n_main;
+      tail_tile = true;
+    }
+  } else {
+    nt = ct % n_nt;
+    b = ct / n_nt;
+  }
+  const int m0 = mt * BM, t0 = nt * BN;
+  const int p0 = t0 - a.pad;  // first activated-input position of the window
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int nchunks = (a.Cin + KC - 1) >> lkc;
+
+  if (wave >= C::NCW) {
+    // ------------------------------------------------------------ producers
+    const int pw = wave - C::NCW;
+    const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
+                      (int)a.x_ts, a.prologue, a.slope};
+    const float* xb = a.x + (int64_t)b * a.x_bs;
+    using PR = Prod<C>;
+    float* const Ws0 = lds;
+    float* const Xa0 = lds + P.xa_off;
+    if constexpr (!ACT) {
+      const int p0a = p0 & ~3;
+      const bool fast = xvec && m0 + BM <= a.M && (a.Cin & (KC - 1)) == 0 && !HSP_DBG(a, 512);  // wave-uniform
+      if (fast) {
+        const float* const wtile = a.w + m0;
+        const float* const xtile = xb + p0a;
+        const int xcs = (int)a.x_cs;
+        const unsigned wofs = 4u * (unsigned)((lane / PR::CPR) * a.w_ld + (lane % PR::CPR) * 4);
+        if (p0a < 0 || p0a + 4 * ((P.xw + 3 + 3) >> 2) > a.Lin) PR::zero_x_rows(P, Xa0, pw, lane);
+        PR::dma_w_fast(wtile, a.w_ld, a.Cin, a.K, P, Ws0, 0, pw, wofs);
+        PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0, 0, p0a, pw, lane);
+        wait_vm0();
+        if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
+        HSP_BARRIER(a);
+        for (int c = 0; c < nchunks; ++c) {
+          const int nb = (c + 1) & 1;
+          if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
+            PR::dma_w_fast(wtile, a.w_ld, a.Cin, a.K, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, pw, wofs);
+            PR::dma_x16_fast(xtile, xcs, a.Lin, P, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0a, pw, lane);
+            wait_vm0();
+            if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
+          }
+          HSP_BARRIER(a);
+        }
+        return;
+      }
+      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
+      if (xvec) PR::dma_x16(pa, P, Xa0, xb, 0, p0a, pw, lane); else PR::dma_x(pa, P, Xa0, xb, 0, p0, pw, lane);
+      wait_vm0();
+      if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0, pw, lane);
+      HSP_BARRIER(a);
+      for (int c = 0; c < nchunks; ++c) {
+        const int nb = (c + 1) & 1;
+        if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
+          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
+          if (xvec) PR::dma_x16(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0a, pw, lane);
+          else PR::dma_x(pa, P, Xa0 + nb * P.xa_sz, xb, (c + 1) << lkc, p0, pw, lane);
+          wait_vm0();
+          if (a.prologue == HSP_PRO_LRELU) PR::lrelu_x(pa, P, Xa0 + nb * P.xa_sz, pw, lane);
+        }
+        HSP_BARRIER(a);
+      }
+    } else {
+      float* const scr = lds + P.scr_off + pw * P.scr_sz;   // raw[2][rpw][xrwp], a2[a2w]
+      float* const a2 = scr + 2 * P.rpw * P.xrwp;
+      const int rsz = P.rpw * P.xrwp;
+      PR::dma_raw(pa, P, scr, xb, 0, p0, pw, lane);
+      PR::dma_w(pa, P, Ws0, 0, m0, pw, lane);
+      wait_vm0();
+      PR::act_rows(pa, P, scr, a2, Xa0, 0, p0, pw, lane);
+      if (nchunks > 1) PR::dma_raw(pa, P, scr + rsz, xb, KC, p0, pw, lane);
+      wait_vm0();
+      HSP_BARRIER(a);
+      for (int c = 0; c < nchunks; ++c) {
+        const int nb = (c + 1) & 1;
+        if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
+          PR::dma_w(pa, P, Ws0 + nb * P.ws_sz, (c + 1) << lkc, m0, pw, lane);
+          if (c + 2 < nchunks) PR::dma_raw(pa, P, scr + (c & 1) * rsz, xb, (c + 2) << lkc, p0, pw, lane);
+          PR::act_rows(pa, P, scr + nb * rsz, a2, Xa0 + nb * P.xa_sz, (c + 1) << lkc, p0, pw, lane);
+          wait_vm0();
+        }
+        HSP_BARRIER(a);
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------- consumers
+  if constexpr (has_tail_path<C, EPI, ACT>()) {
+    if (tail_tile) {
+      // <= 32 valid columns: wave w takes rows 32 w .. 32 w + 31 of the tile and the first 32 columns
+      conv_consume<C, EPI, ACT, 1, 1>(a, P, lds, b, m0, t0, p0, wave, 0, lane, nchunks, lkc, xvec);
+      return;
+    }
+  }
+  conv_consume<C, EPI, ACT, TM, TN>(a, P, lds, b, m0, t0, p0, wave / C::kWN, wave % C::kWN, lane, nchunks, lkc, xvec);
+}
+
 // -------------------------------------------------------------------- host side
 constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr int kLdsTarget = 80 * 1024;  // two workgroups per CU when possible
@@ -953,8 +1014,29 @@ int launch_one(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   }
   const int n_mt = (a.M + C::BM - 1) / C::BM;
   const int n_nt = (a.ncols + C::BN - 1) / C::BN;
-  const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
+  // block schedule (see the kernel): row tiles per XCD group, narrow tail tiles
+  const int64_t n_ct = (int64_t)n_nt * a.B;
+  // g > 0 (XCD-grouped row tiles) is a measured LOSS and exists in the tuning build only (debug bit 16384):
+  // k = 3 convs run 4-5 % slower with it (C = 512 / L = 800: 114.5 vs 119.9 TFLOP/s, C = 256 / L = 4000: 120.9 vs
+  // 126.2), k = 7 / 11 are unchanged (profiles/r03_sched_sweep.txt) -- the blocks of one XCD sharing ONE weight slab
+  // matters more than fetching a window once.
+  int g = 0;
+  if (HSP_DBG(a, 16384) && n_mt >= 1 && n_mt <= 8 && (8 % n_mt) == 0) {
+    // the largest group of row tiles whose weight slabs share one XCD's 4-MB L2 with room for the streamed windows
+    const int64_t slab = (int64_t)a.K * a.Cin * C::BM * (int64_t)sizeof(float);
+    g = 1;
+    for (int cand = n_mt; cand > 1; cand >>= 1)
+      if (n_mt % cand == 0 && (int64_t)cand * slab <= (int64_t)3200 * 1024) { g = cand; break; }
+  }
+  const int rem = a.ncols - (n_nt - 1) * C::BN;
+  const int tail = (has_tail_path<C, EPI, ACT>() && n_nt >= 2 && rem <= 32 && !HSP_DBG(a, 32768)) ? 1 : 0;
+  int64_t blocks = (int64_t)n_mt * n_ct;
+  if (g > 0) {
+    const int nx = 8 / (n_mt / g);
+    blocks = 8 * (int64_t)g * ((n_ct + nx - 1) / nx);
+  }
   if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
+  const int sched = g | (tail << 8);
   auto kern = conv1d_mfma_kernel<C, EPI, ACT>;
   // raise the kernel's dynamic-LDS cap once per device (the attribute is per device; kept out of the
   // launch path afterwards so that launches are legal inside a hipGraph stream capture)
@@ -966,7 +1048,7 @@ int launch_one(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool xvec = !ACT && a.x_ts == 1 && (a.Lin & 3) == 0 && (a.x_cs & 3) == 0 && (a.x_bs & 3) == 0 && al16(a.x) &&
                     !HSP_DBG(a, 64);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc, xvec ? 1 : 0);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, s, a, n_mt, n_nt, lkc, xvec ? 1 : 0, sched);
   return (int)hipGetLastError();
 }
 
