@@ -6,6 +6,7 @@
 // One thread per output sample, time fastest (coalesced x reads and y writes; the
 // weight read w[j][ci][co] is wave-uniform when a wave covers one channel, and
 // coalesced over co when L == 1).
+#include <type_traits>
 #include "hsp_device.h"
 
 namespace {
@@ -58,6 +59,106 @@ __global__ __launch_bounds__(256) void conv1d_direct_kernel(const hsp_conv1d_arg
   }
 }
 
+// One output channel, unit stride / dilation, K <= 9, 16-B addressable rows with L % 4 == 0: conv_post of both
+// Generators (C -> 1, k = 7, + tanh: hierspeechpp_speechsynthesizer.py:449-450, speechsr48k/speechsr.py:106-107) and of
+// the SourceNetwork.  The one-thread-per-output kernel above ran it at 3.6 TFLOP/s (0.25 ms per 32 x 4 s step: a
+// dependent chain of C x K scalar loads per output).  Here a thread owns FOUR consecutive outputs: per channel it
+// loads the three aligned float4 that cover t - 4 .. t + 7 (neighbouring lanes overlap: those re-reads hit the L1),
+// all channels' loads independent, and the K x 4 FMAs run from registers; the C x K weights sit in LDS (broadcast
+// reads).  HBM-bound on the input: ~5 TB/s.
+constexpr int C1_MAXW = 4096;   // C * K floats of weights in LDS
+
+template <int N, class F>
+__device__ __forceinline__ void c1_static_for(F&& f) {
+  if constexpr (N > 0) {
+    c1_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int K>   // odd, <= 9: the window t - 4 .. t + 7 covers every tap of the four outputs
+__global__ __launch_bounds__(256) void conv1d_cout1_kernel(const hsp_conv1d_args a, int n_tiles) {
+  constexpr int H = (K - 1) / 2, CU = 4;   // CU channels' loads in flight at a time
+  __shared__ float ws[C1_MAXW];
+  for (int e = threadIdx.x; e < a.Cin * K; e += 256) {
+    const int c = e / K, j = e - c * K;
+    ws[e] = a.w[((int64_t)j * a.Cin + c) * a.w_ld];
+  }
+  __syncthreads();
+  const int tile = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
+  const int t = tile * 1024 + 4 * threadIdx.x;          // first of this thread's four outputs
+  if (t >= a.Lout) return;
+  const int L = a.Lin;
+  const float* xb = a.x + (int64_t)b * a.x_bs + t;
+  const int64_t xcs = a.x_cs;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  const bool lo = t - 4 >= 0, hi = t + 4 < L;           // t .. t + 3 is inside: L % 4 == 0
+  // every index below is a compile-time constant (c1_static_for): a runtime index would put the staged
+  // float4s in scratch memory.  Loads are unconditional, from clamped (always legal) addresses, and the zero
+  // padding is selected afterwards: a load in a divergent block gets an s_waitcnt vmcnt(0) behind it and the
+  // round trips of a group serialise.
+  const int offl = lo ? -4 : 0, offh = hi ? 4 : 0;
+  const int ngroups = a.Cin / CU;
+  for (int g = 0; g < ngroups; ++g) {
+    const float* xc = xb + (int64_t)(g * CU) * xcs;
+    float4 va[CU], vb[CU], vc[CU];
+    c1_static_for<CU>([&](auto uu) __attribute__((always_inline)) {
+      constexpr int u = decltype(uu)::value;
+      va[u] = *reinterpret_cast<const float4*>(xc + u * xcs + offl);
+      vb[u] = *reinterpret_cast<const float4*>(xc + u * xcs);
+      vc[u] = *reinterpret_cast<const float4*>(xc + u * xcs + offh);
+    });
+    c1_static_for<CU>([&](auto uu) __attribute__((always_inline)) {
+      constexpr int u = decltype(uu)::value;
+      const float w_[12] = {lo ? va[u].x : 0.f, lo ? va[u].y : 0.f, lo ? va[u].z : 0.f, lo ? va[u].w : 0.f,
+                            vb[u].x, vb[u].y, vb[u].z, vb[u].w,
+                            hi ? vc[u].x : 0.f, hi ? vc[u].y : 0.f, hi ? vc[u].z : 0.f, hi ? vc[u].w : 0.f};
+      const float* wc = ws + (g * CU + u) * K;
+      c1_static_for<K>([&](auto jj) __attribute__((always_inline)) {
+        constexpr int j = decltype(jj)::value;
+        const float wj = wc[j];
+        acc0 = fmaf(wj, w_[4 + j - H], acc0);       // x[t + q + j - H], q = 0 .. 3
+        acc1 = fmaf(wj, w_[5 + j - H], acc1);
+        acc2 = fmaf(wj, w_[6 + j - H], acc2);
+        acc3 = fmaf(wj, w_[7 + j - H], acc3);
+      });
+    });
+  }
+  for (int c = ngroups * CU; c < a.Cin; ++c) {          // channel tail (Cin % CU)
+    const float* xc = xb + (int64_t)c * xcs;
+    const float4 va = *reinterpret_cast<const float4*>(xc + offl);
+    const float4 vb = *reinterpret_cast<const float4*>(xc);
+    const float4 vc = *reinterpret_cast<const float4*>(xc + offh);
+    const float w_[12] = {lo ? va.x : 0.f, lo ? va.y : 0.f, lo ? va.z : 0.f, lo ? va.w : 0.f, vb.x, vb.y, vb.z, vb.w,
+                          hi ? vc.x : 0.f, hi ? vc.y : 0.f, hi ? vc.z : 0.f, hi ? vc.w : 0.f};
+    const float* wc = ws + c * K;
+    c1_static_for<K>([&](auto jj) __attribute__((always_inline)) {
+      constexpr int j = decltype(jj)::value;
+      const float wj = wc[j];
+      acc0 = fmaf(wj, w_[4 + j - H], acc0);
+      acc1 = fmaf(wj, w_[5 + j - H], acc1);
+      acc2 = fmaf(wj, w_[6 + j - H], acc2);
+      acc3 = fmaf(wj, w_[7 + j - H], acc3);
+    });
+  }
+  const float bz = a.bias ? a.bias[0] : 0.0f;
+  const float sc = a.scale * a.post_scale;
+  float4 o;
+  o.x = hsp_apply_act(acc0 + bz, a.act) * sc;
+  o.y = hsp_apply_act(acc1 + bz, a.act) * sc;
+  o.z = hsp_apply_act(acc2 + bz, a.act) * sc;
+  o.w = hsp_apply_act(acc3 + bz, a.act) * sc;
+  *reinterpret_cast<float4*>(a.y + (int64_t)b * a.y_bs + t) = o;
+}
+
+bool cout1_fast(const hsp_conv1d_args& a) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return a.Cout == 1 && a.stride == 1 && a.dil == 1 && a.K <= 9 && (a.K & 1) && a.pad == (a.K - 1) / 2 && a.x_ts == 1 &&
+         a.Lin == a.Lout && (a.Lin & 3) == 0 && (a.x_cs & 3) == 0 && (a.x_bs & 3) == 0 && (a.y_bs & 3) == 0 && al16(a.x) &&
+         al16(a.y) && a.prologue == HSP_PRO_NONE && !a.cbias && !a.cscale && !a.res && !a.accumulate &&
+         a.mask_mode == HSP_MASK_NONE && (int64_t)a.Cin * a.K <= C1_MAXW;
+}
+
 }  // namespace
 
 extern "C" int hsp_conv1d_direct_f32(const hsp_conv1d_args* ap, void* stream) {
@@ -69,6 +170,20 @@ extern "C" int hsp_conv1d_direct_f32(const hsp_conv1d_args* ap, void* stream) {
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_SILU) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
   if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused LayerNorm / second output: token-GEMM path only
+  if (cout1_fast(a)) {
+    const int n_tiles = (a.Lout + 1023) / 1024;
+    const int64_t nb = (int64_t)n_tiles * a.B;
+    if (nb > 0x7fffffff) return HSP_EINVAL;
+    const hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (a.K) {
+      case 1: hipLaunchKernelGGL(conv1d_cout1_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, a, n_tiles); break;
+      case 3: hipLaunchKernelGGL(conv1d_cout1_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, a, n_tiles); break;
+      case 5: hipLaunchKernelGGL(conv1d_cout1_kernel<5>, dim3((unsigned)nb), dim3(256), 0, st, a, n_tiles); break;
+      case 7: hipLaunchKernelGGL(conv1d_cout1_kernel<7>, dim3((unsigned)nb), dim3(256), 0, st, a, n_tiles); break;
+      default: hipLaunchKernelGGL(conv1d_cout1_kernel<9>, dim3((unsigned)nb), dim3(256), 0, st, a, n_tiles); break;
+    }
+    return (int)hipGetLastError();
+  }
   const int64_t total = (int64_t)a.B * a.Cout * a.Lout;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 262144) blocks = 262144;

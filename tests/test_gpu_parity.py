@@ -298,6 +298,37 @@ def test_wn_and_attention_longer_ragged(device):
     _close(got, ref, "dit T=333")
 
 
+@pytest.mark.parametrize("C_,K,L,B", [(32, 7, 2500, 2), (32, 7, 1024, 1), (3, 7, 1032, 2), (4, 3, 36, 1), (4, 7, 4, 2),
+                                       (3, 1, 8, 1), (128, 7, 800, 2), (5, 9, 2056, 1), (5, 5, 37, 1), (6, 11, 400, 1)])
+def test_activation_post_conv_post_tanh_vs_oracle(C_, K, L, B, device):
+    """activation_post -> conv_post -> tanh (the tail of both Generators) against the oracle's three steps: lengths on
+    both sides of the one-output-channel conv kernel's 1 024-sample tile and shorter than the filters' support,
+    L % 4 != 0 and K = 11 (which take the generic direct kernel)."""
+    from oracle import hsp_oracle as O
+    from megatts2_hierspeechpp_amd import _lib as L_
+    from megatts2_hierspeechpp_amd import activations, hip_layers
+    from megatts2_hierspeechpp_amd.alias_free_torch import Activation1d
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.activation_post = Activation1d(activations.SnakeBeta(C_, alpha_logscale=True))
+            self.conv_post = hip_layers.Conv1d(C_, 1, K, padding=(K - 1) // 2, bias=False)
+
+    g = torch.Generator().manual_seed(C_ * 100 + L)
+    m = M()
+    m.activation_post.act.alpha.data = 0.5 * torch.randn(C_, generator=g)
+    m.activation_post.act.beta.data = 0.5 * torch.randn(C_, generator=g)
+    m.conv_post.weight.data = 0.3 * torch.randn(1, C_, K, generator=g)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    hip_layers.finalize(m, device)
+    x = torch.randn(B, C_, L, generator=g)
+    a = O.act1d(sd, "activation_post", x)
+    ref = torch.tanh(torch.nn.functional.conv1d(a, sd["conv_post.weight"], padding=(K - 1) // 2)).numpy()
+    got = m.conv_post(m.activation_post(x.to(device)), act=L_.ACT_TANH).cpu().numpy()
+    _close(got, ref, f"post C={C_} K={K} L={L}")
+
+
 def test_wn_with_dilation_rate_2_vs_oracle(device):
     """modules.WN(dilation_rate = 2, 5 layers): dilations 1 ... 16, the last in-layer's halo (67 columns) takes the
     wide-pitch gated tile shape; both launch policies (layer by layer / the fused entry point's own fallback)."""
