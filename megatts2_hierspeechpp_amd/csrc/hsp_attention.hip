@@ -633,6 +633,172 @@ int mha_stream_launch(const hsp_mha_args& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Short-sequence attention without masks or window (the PLM loop's 4 x 69 heads over a growing prefix, timm
+// Attention of the DiT blocks: Tk <= 256): latency-oriented.  The whole-row MFMA kernel above stages V through LDS
+// (by LDS-DMA or slab by slab) and spends 20 us on a 10-key problem, 56 us at 200 keys (round-3 trace of the PLM
+// loop: 4 launches x 200 steps = a quarter of the loop).  Here nothing but the scores touches LDS:
+//   * one workgroup (8 waves) = 32 queries of one (batch, head);
+//   * S = (scale Q)^T K: wave w owns key blocks w, w + 8, ...; both fragments are coalesced dword loads from the
+//     channel-major planes (lanes along queries / keys), the Q fragments are loaded once and kept in registers;
+//   * row softmax in LDS, 4 rows per wave;
+//   * O^T = V P^T: six (three, ...) waves = head-dim blocks x two key halves.  The V fragment of lane (d, half) is ONE
+//     16-B load of V[d][j0 + 4 half .. + 3] feeding four MFMAs (the k-slots of an MFMA may pair any two keys as
+//     long as the P fragment pairs the same ones), so V needs no transpose and no staging; the two key halves
+//     are added through LDS.
+// LDS = 32 x (Tk + pad) scores + the partial-sum buffer: 45 KB at Tk = 256 -> three workgroups per CU.
+constexpr int TQT = 32;
+
+template <int NDB>
+__global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int n_qt, int sp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = a.D, Tq = a.Tq, Tk = a.Tk;
+  float* S = lds;                        // [32][sp]
+  float* red = S + 32 * sp;              // [NDB][16][64] partial O of the second key half
+  float* inv_s = red + NDB * 16 * 64;    // [32]
+  int bid = blockIdx.x;
+  const int qt = bid % n_qt;
+  bid /= n_qt;
+  const int h = bid % a.H;
+  const int b = bid / a.H;
+  const int i0 = qt * TQT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  const int64_t qcs = a.q_cs, kcs = a.k_cs, vcs = a.v_cs, ocs = a.o_cs;
+  const float* qh = a.q + (int64_t)b * a.q_bs + (int64_t)h * D * qcs;
+  const float* kh = a.k + (int64_t)b * a.k_bs + (int64_t)h * D * kcs;
+  const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
+  float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
+  const int nkb = (Tk + 31) >> 5;
+
+  // ---- scores.  Tk <= 256 = eight key blocks = one per wave, so nothing is reused across blocks: both fragments
+  // are loaded per group of 8 k-steps, the next group in flight under this group's MFMAs (the loop of
+  // hsp_rgemm.hip).  Only ceil(D / 2) k-steps run (35 of the padded 48 at D = 69).
+  {
+    constexpr int U = 8;
+    const int ksteps = (D + 1) >> 1;
+    const bool odd_tail = (D & 1) != 0;
+    const int iq = min(i0 + l32, Tq - 1);
+    for (int jb = wave; jb < nkb; jb += 8) {
+      const int j = jb * 32 + l32;
+      const float* qp = qh + iq + (int64_t)half * qcs;
+      const float* kp = kh + min(j, Tk - 1) + (int64_t)half * kcs;
+      const int64_t qst = 2 * qcs, kst = 2 * kcs;
+      auto loadg = [&](int kk, float (&Q)[U], float (&Kf)[U]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = min(kk + u, ksteps - 1);
+          const int kc = (odd_tail && half == 1 && k == ksteps - 1) ? k - 1 : k;   // stay inside the head's rows
+          Q[u] = qp[(int64_t)kc * qst];
+          Kf[u] = kp[(int64_t)kc * kst];
+        }
+      };
+      mha_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      float fq[U], fk[U];
+      loadg(0, fq, fk);
+#pragma unroll 1
+      for (int kk = 0; kk < ksteps; kk += U) {
+        float nq[U], nk[U];
+        const bool more = kk + U < ksteps;
+        if (more) loadg(kk + U, nq, nk);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool ok = kk + u < ksteps && !(odd_tail && half == 1 && kk + u == ksteps - 1);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? fq[u] * a.qk_scale : 0.0f, fk[u], acc, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) { fq[u] = nq[u]; fk[u] = nk[u]; }
+        }
+      }
+      const bool jok = j < Tk;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * half) * sp + j] = jok ? acc[r] : -3.0e38f;
+    }
+  }
+  __syncthreads();
+  // ---- row softmax, 4 rows per wave; P is left un-normalised, 1 / sum goes to the output
+  const int ncol = nkb * 32;                          // columns written above (the padding holds -3e38 -> 0)
+  for (int u = 0; u < 4; ++u) {
+    const int row_i = wave * 4 + u;
+    float* row = S + row_i * sp;
+    float mx = -3.0e38f;
+    for (int j = lane; j < ncol; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int j = lane; j < ncol; j += 64) {
+      const float sv = row[j];
+      const float e = sv > -1.0e38f ? __builtin_amdgcn_exp2f((sv - mx) * 1.4426950408889634f) : 0.0f;
+      row[j] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) inv_s[row_i] = 1.0f / sum;
+  }
+  // zero the columns [ncol, ncol8) the PV groups of eight keys may read
+  {
+    const int ncol8 = (ncol + 7) & ~7;
+    for (int e = tid; e < 32 * (ncol8 - ncol); e += 512) S[(e / (ncol8 - ncol)) * sp + ncol + e % (ncol8 - ncol)] = 0.0f;
+  }
+  __syncthreads();
+  // ---- O^T[d][q] = sum_j V[d][j] P[q][j]: wave = (head-dim block, key half); groups of 8 keys
+  const int db = wave % NDB, kh2 = wave / NDB;        // waves >= 2 NDB idle
+  mha_f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
+  if (kh2 < 2) {
+    const int ngrp = (Tk + 7) >> 3;                   // groups of 8 keys
+    const int g0 = kh2 == 0 ? 0 : (ngrp + 1) / 2, g1 = kh2 == 0 ? (ngrp + 1) / 2 : ngrp;
+    const int d = db * 32 + l32;
+    const bool dok = d < D;
+    const float* vrow = vh + (int64_t)min(d, D - 1) * vcs;
+    const float* prow = S + l32 * sp + 4 * half;
+    for (int g = g0; g < g1; ++g) {
+      const int j0 = 8 * g + 4 * half;                // this lane's four keys
+      float v4[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) v4[qq] = (dok && j0 + qq < Tk) ? vrow[min(j0 + qq, Tk - 1)] : 0.0f;
+      const float* pp = prow + 8 * g;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[qq], pp[qq], oacc, 0, 0, 0);
+    }
+    if (kh2 == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(db * 16 + r) * 64 + lane] = oacc[r];
+    }
+  }
+  __syncthreads();
+  if (kh2 == 0 && i0 + l32 < Tq) {
+    const float inv = inv_s[l32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = (oacc[r] + red[(db * 16 + r) * 64 + lane]) * inv;
+    }
+  }
+}
+
+template <int NDB>
+int mha_tok_launch(const hsp_mha_args& a, hipStream_t stream) {
+  const int nkb = (a.Tk + 31) >> 5;
+  const int sp = ((nkb * 32 + 7) & ~7) + 1;
+  const size_t lds_bytes = ((size_t)32 * sp + NDB * 16 * 64 + 32) * sizeof(float);
+  const int n_qt = (a.Tq + TQT - 1) / TQT;
+  const int64_t blocks = (int64_t)n_qt * a.H * a.B;
+  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
+  static hsp_lds_flags flags;
+  if (lds_bytes > 32 * 1024)
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_tok_kernel<NDB>), (int)lds_bytes, flags)) return e;
+  hipLaunchKernelGGL((mha_tok_kernel<NDB>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, a, n_qt, sp);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
@@ -656,6 +822,14 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   // queries fit LDS, the key-streaming one (online softmax) beyond
   if (!a.rel_k && !a.rel_v && a.D <= 128) {
     int e = -1;
+    // no masks, at most 256 keys: the latency-oriented kernel (NDB <= 3: two key halves x head-dim blocks = 6 waves)
+    if (!force_stream && !a.mask_q && !a.mask_dense && a.Tk <= 256 && a.D <= 96) {
+      switch ((a.D + 31) / 32) {
+        case 1: return mha_tok_launch<1>(a, st);
+        case 2: return mha_tok_launch<2>(a, st);
+        default: return mha_tok_launch<3>(a, st);
+      }
+    }
     if (!force_stream) {
       switch ((a.D + 31) / 32) {
         case 1: e = mha_mfma_launch<1>(a, st); break;

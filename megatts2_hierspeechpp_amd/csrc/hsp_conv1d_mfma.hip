@@ -6,6 +6,7 @@
 #include "hsp_conv1d_mfma_kernel.h"
 
 int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);  // hsp_tokgemm.hip; -1 = shape not taken
+int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);    // hsp_rgemm.hip; likewise
 
 namespace {
 using namespace hspconv;
@@ -48,7 +49,12 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // ties up to 128 and loses 2x beyond (tools/conv_sweep.py, profiles/r02_tile_threshold.txt).
   const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B <= 128;
   if ((short_seq || a.ln_c1 || a.split_row) && !HSP_DBG(a, 128)) {
-    // 1x1 GEMMs over a few thousand token columns: the latency-oriented kernel (hsp_tokgemm.hip)
+    // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip), else the LDS-DMA
+    // token GEMM (hsp_tokgemm.hip: second-output launches; tuning bit 131072 forces it for A/B runs)
+    if (!HSP_DBG(a, 131072)) {
+      const int e = hsp_rgemm_try(a, s, plan_out);
+      if (e >= 0) return e;
+    }
     const int e = hsp_tokgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }

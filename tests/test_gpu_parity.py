@@ -829,9 +829,13 @@ def test_second_output_gemm_matches_two_launches(device):
         out_new = lay(acts, row_range=(H_, 2 * H_))
         both = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, prev.clone(), True))
         assert both is not None, (H_, B, T)
-        assert torch.equal(both[0], x_ref) and torch.equal(both[1], out_ref)
+        # the two single-output launches take the register-path GEMM, the second-output launch the LDS-DMA token GEMM:
+        # same products, another summation order (K split across waves) -> equal to fp32 rounding, not bit for bit
+        _close(both[0].cpu().numpy(), x_ref.cpu().numpy(), "split: first output")
+        _close(both[1].cpu().numpy(), out_ref.cpu().numpy(), "split: accumulated second output")
         first = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, None, False))
-        assert torch.equal(first[0], x_ref) and torch.equal(first[1], out_new)
+        _close(first[0].cpu().numpy(), x_ref.cpu().numpy(), "split: first output (fresh second)")
+        _close(first[1].cpu().numpy(), out_new.cpu().numpy(), "split: fresh second output")
     # no fused kernel: split row off the 64-row tile grid, or a column count the token GEMM does not take
     lay = Conv1d(96, 192, 1, weight_norm=True)
     finalize(lay, device)
