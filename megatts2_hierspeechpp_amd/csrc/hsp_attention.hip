@@ -628,7 +628,7 @@ int mha_stream_launch(const hsp_mha_args& a, hipStream_t stream) {
   if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
   static hsp_lds_flags flags;
   if (lds_bytes > 32 * 1024)
-    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_stream_kernel), (int)lds_bytes, flags)) return e;
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_stream_kernel), 160 * 1024, flags)) return e;   // once per device: the maximum
   hipLaunchKernelGGL(mha_stream_kernel, dim3((unsigned)blocks), dim3(ATT_THREADS), lds_bytes, stream, a, n_qt, dpad);
   return (int)hipGetLastError();
 }
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
   // are loaded per group of 8 k-steps, the next group in flight under this group's MFMAs (the loop of
   // hsp_rgemm.hip).  Only ceil(D / 2) k-steps run (35 of the padded 48 at D = 69).
   {
-    constexpr int U = 8;
+    constexpr int U = 18;                             // 35 k-steps at D = 69: two round trips (48 at D = 96: three)
     const int ksteps = (D + 1) >> 1;
     const bool odd_tail = (D & 1) != 0;
     const int iq = min(i0 + l32, Tq - 1);
@@ -686,33 +686,23 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
       const float* qp = qh + iq + (int64_t)half * qcs;
       const float* kp = kh + min(j, Tk - 1) + (int64_t)half * kcs;
       const int64_t qst = 2 * qcs, kst = 2 * kcs;
-      auto loadg = [&](int kk, float (&Q)[U], float (&Kf)[U]) __attribute__((always_inline)) {
+      mha_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 1
+      for (int kk = 0; kk < ksteps; kk += U) {
+        float fq[U], fk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int k = min(kk + u, ksteps - 1);
           const int kc = (odd_tail && half == 1 && k == ksteps - 1) ? k - 1 : k;   // stay inside the head's rows
-          Q[u] = qp[(int64_t)kc * qst];
-          Kf[u] = kp[(int64_t)kc * kst];
+          fq[u] = qp[(int64_t)kc * qst];
+          fk[u] = kp[(int64_t)kc * kst];
         }
-      };
-      mha_f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      float fq[U], fk[U];
-      loadg(0, fq, fk);
-#pragma unroll 1
-      for (int kk = 0; kk < ksteps; kk += U) {
-        float nq[U], nk[U];
-        const bool more = kk + U < ksteps;
-        if (more) loadg(kk + U, nq, nk);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool ok = kk + u < ksteps && !(odd_tail && half == 1 && kk + u == ksteps - 1);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? fq[u] * a.qk_scale : 0.0f, fk[u], acc, 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) { fq[u] = nq[u]; fk[u] = nk[u]; }
         }
       }
       const bool jok = j < Tk;
@@ -721,6 +711,28 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
     }
   }
   __syncthreads();
+  // ---- V fragments: requested NOW, ahead of the softmax they do not depend on (one exposed round trip less).
+  // O^T[d][q] = sum_j V[d][j] P[q][j]: wave = (head-dim block, key half); groups of 8 keys, ALL of a wave's fragments
+  // (<= 16 groups at Tk <= 256) in flight at once.
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int MAXG = 16;
+  const int db = wave % NDB, kh2 = wave / NDB;        // waves >= 2 NDB idle in the PV phase
+  const int ngrp = (Tk + 7) >> 3;                     // groups of 8 keys
+  const int g0 = kh2 == 0 ? 0 : (ngrp + 1) / 2, g1 = kh2 >= 2 ? 0 : (kh2 == 0 ? (ngrp + 1) / 2 : ngrp);
+  const int dv = db * 32 + l32;
+  const bool dok = dv < D;
+  // lane (d, half) wants V[d][jl .. jl + 3], jl = 8 g + 4 half: one 16-B load (4-B aligned: the utterances of a
+  // batch sit side by side on the column axis).  A window that would end beyond Tk (last group only) is moved
+  // back inside the row -- Tk >= 4 here -- and re-indexed below; what lies beyond Tk is zero.
+  f4u v[MAXG];
+  {
+    const float* vrow = vh + (int64_t)min(dv, D - 1) * vcs;
+#pragma unroll
+    for (int u = 0; u < MAXG; ++u) {
+      const int jl = 8 * (g0 + u) + 4 * half;
+      if (g0 + u < g1) v[u] = *reinterpret_cast<const f4u*>(vrow + max(min(jl, Tk - 4), 0));
+    }
+  }
   // ---- row softmax, 4 rows per wave; P is left un-normalised, 1 / sum goes to the output
   const int ncol = nkb * 32;                          // columns written above (the padding holds -3e38 -> 0)
   for (int u = 0; u < 4; ++u) {
@@ -747,26 +759,28 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
     for (int e = tid; e < 32 * (ncol8 - ncol); e += 512) S[(e / (ncol8 - ncol)) * sp + ncol + e % (ncol8 - ncol)] = 0.0f;
   }
   __syncthreads();
-  // ---- O^T[d][q] = sum_j V[d][j] P[q][j]: wave = (head-dim block, key half); groups of 8 keys
-  const int db = wave % NDB, kh2 = wave / NDB;        // waves >= 2 NDB idle
+  // ---- O^T += V P^T on the fragments requested above
   mha_f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
   if (kh2 < 2) {
-    const int ngrp = (Tk + 7) >> 3;                   // groups of 8 keys
-    const int g0 = kh2 == 0 ? 0 : (ngrp + 1) / 2, g1 = kh2 == 0 ? (ngrp + 1) / 2 : ngrp;
-    const int d = db * 32 + l32;
-    const bool dok = d < D;
-    const float* vrow = vh + (int64_t)min(d, D - 1) * vcs;
     const float* prow = S + l32 * sp + 4 * half;
-    for (int g = g0; g < g1; ++g) {
-      const int j0 = 8 * g + 4 * half;                // this lane's four keys
-      float v4[4];
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) v4[qq] = (dok && j0 + qq < Tk) ? vrow[min(j0 + qq, Tk - 1)] : 0.0f;
-      const float* pp = prow + 8 * g;
+    for (int u = 0; u < MAXG; ++u) {
+      if (g0 + u < g1) {
+        const int jl = 8 * (g0 + u) + 4 * half;
+        const int sh = jl - max(min(jl, Tk - 4), 0);  // 0 except in the last group
+        float v4[4];
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[qq], pp[qq], oacc, 0, 0, 0);
+        for (int qq = 0; qq < 4; ++qq) {
+          const int idx = qq + sh;                    // position of key jl + qq inside the loaded window
+          const float val = idx == 0 ? v[u][0] : idx == 1 ? v[u][1] : idx == 2 ? v[u][2] : idx == 3 ? v[u][3] : 0.0f;
+          v4[qq] = dok ? val : 0.0f;
+        }
+        const float* pp = prow + 8 * (g0 + u);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[qq], pp[qq], oacc, 0, 0, 0);
+      }
     }
     if (kh2 == 1) {
 #pragma unroll
@@ -792,9 +806,10 @@ int mha_tok_launch(const hsp_mha_args& a, hipStream_t stream) {
   const int n_qt = (a.Tq + TQT - 1) / TQT;
   const int64_t blocks = (int64_t)n_qt * a.H * a.B;
   if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
-  static hsp_lds_flags flags;
+  static hsp_lds_flags flags;   // raised ONCE per device, so to the kernel's maximum (Tk = 256), not to this launch's size
+  constexpr int kMaxLds = (32 * 265 + NDB * 16 * 64 + 32) * (int)sizeof(float);
   if (lds_bytes > 32 * 1024)
-    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_tok_kernel<NDB>), (int)lds_bytes, flags)) return e;
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_tok_kernel<NDB>), kMaxLds, flags)) return e;
   hipLaunchKernelGGL((mha_tok_kernel<NDB>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, a, n_qt, sp);
   return (int)hipGetLastError();
 }
@@ -823,7 +838,7 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   if (!a.rel_k && !a.rel_v && a.D <= 128) {
     int e = -1;
     // no masks, at most 256 keys: the latency-oriented kernel (NDB <= 3: two key halves x head-dim blocks = 6 waves)
-    if (!force_stream && !a.mask_q && !a.mask_dense && a.Tk <= 256 && a.D <= 96) {
+    if (!force_stream && !a.mask_q && !a.mask_dense && a.Tk >= 4 && a.Tk <= 256 && a.D <= 96) {
       switch ((a.D + 31) / 32) {
         case 1: return mha_tok_launch<1>(a, st);
         case 2: return mha_tok_launch<2>(a, st);

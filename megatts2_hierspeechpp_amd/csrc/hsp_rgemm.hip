@@ -12,7 +12,7 @@
 // [K][N], so BOTH MFMA fragments of v_mfma_f32_32x32x2_f32 are plain coalesced dword loads: lane (l32, half) reads
 // W[2 kk + half][m0 + l32] and X[2 kk + half][n0 + l32] -- 128 contiguous bytes per half wave, straight from L2
 // (weights) / L2-MALL (activations) into the registers the MFMA reads.  A workgroup is 8 waves on ONE small output
-// tile (32 x 32, 64 x 32 or 64 x 64): the waves split the tile's 32 x 32 blocks AND its K range, each wave runs a
+// tile (32 x 32 or 64 x 32): the waves split the tile's 32 x 32 blocks AND its K range, each wave runs a
 // register-prefetched chain of K / (2 ksplit) MFMAs, and the partial sums meet in LDS.  Many small workgroups
 // instead of a few pipelined ones: 4 of them share a CU, so one wave's load latency is another's MFMA time, and a
 // launch is one L2 round trip + a short MFMA chain + one LDS exchange.
@@ -32,9 +32,13 @@ namespace {
 
 typedef float rg_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int RG_WAVES = 8;
-constexpr int RG_U = 8;   // k-steps per register group (16 loads in flight per wave while the previous group multiplies)
+// RG_U = k-steps per register group: 2 RG_U loads requested together, then their RG_U MFMAs.  A launch at these sizes
+// is a chain of L2 round trips (1-2 us each) around 0.5 us of MFMAs, so the group covers a wave's WHOLE share of K where
+// registers allow: 18 k-steps at K = 276 with the K range split eight ways (one round trip; groups of 8 with the next
+// group prefetched made it three -- the prefetch hides 0.2 us of MFMAs, not the trip), 36 for K > 512 (K = 1104: two).
 
-// cfg: nbm x nbn blocks of 32 x 32 per workgroup, ksplit = 8 / (nbm * nbn) waves per block
+// cfg: nbm x nbn blocks of 32 x 32 per workgroup (1 x 1 or 2 x 1), ksplit = 8 / (nbm * nbn) waves per block
+template <int RG_U>
 __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_args a, int n_mt, int n_nt, int nbm,
                                                               int nbn) {
   __shared__ float part[RG_WAVES][16][64];      // partial accumulators (32 KB)
@@ -60,20 +64,20 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
   const int m = min(mb + l32, a.M - 1);
   const int n = min(nb + l32, a.ncols - 1);
   const float* wp = a.w + m + (int64_t)half * a.w_ld;
-  const float* xp = a.x + (int64_t)b * a.x_bs + n + (int64_t)half * a.x_cs;
+  const float* xp = a.x + (int64_t)b * a.x_bs + (int64_t)n * a.x_ts + (int64_t)half * a.x_cs;
   const int64_t wst = 2 * (int64_t)a.w_ld, xst = 2 * a.x_cs;
   const bool odd_tail = (K & 1) != 0;           // the last k-step's second channel does not exist
 
   // ---- epilogue operands of the accumulator rows this wave finalises (r = ks, ks + ksplit, ...): fetched now
-  const int nr = 16 / ksplit;                   // 2, 4 or 8
+  const int nr = 16 / ksplit;                   // 2 or 4 (ksplit 8 / 4)
   const int ncol = nb + l32;
   const int nc = min(ncol, a.ncols - 1);
   const float mk = a.mask_mode != HSP_MASK_NONE ? a.mask[(int64_t)b * a.mask_bs + nc] : 1.0f;
   const float* resb = a.res ? a.res + (int64_t)b * a.res_bs + nc : nullptr;
   float* yb = a.y + (int64_t)b * a.y_bs + nc;
-  float bv[8], rv[8], yv[8], cs[8], c1[8];
+  float bv[4], rv[4], yv[4], cs[4], c1[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     bv[i] = rv[i] = yv[i] = c1[i] = 0.0f;
     cs[i] = 1.0f;
     if (i < nr) {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
       if (a.ln_c1) c1[i] = a.ln_c1[mr];
     }
   }
-  const float pivot = a.ln_c1 ? a.x[(int64_t)b * a.x_bs + n] : 0.0f;   // channel 0 of this lane's column
+  const float pivot = a.ln_c1 ? a.x[(int64_t)b * a.x_bs + (int64_t)n * a.x_ts] : 0.0f;   // channel 0 of this lane's column
 
   // ---- main loop: groups of RG_U k-steps, the next group's fragments in flight under this group's MFMAs
   rg_f32x16 acc;
@@ -104,12 +108,10 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
       B[u] = xp[(int64_t)k * xst];
     }
   };
-  if (kk0 < kk1 && !RG_DBG(a, 2)) {
-    load(kk0, fa, fb);
+  if (!RG_DBG(a, 2)) {
+#pragma unroll 1
     for (int kk = kk0; kk < kk1; kk += RG_U) {
-      float na[RG_U], nbf[RG_U];
-      const bool more = kk + RG_U < kk1;
-      if (more) load(kk + RG_U, na, nbf);
+      load(kk, fa, fb);
 #pragma unroll
       for (int u = 0; u < RG_U; ++u) {
         const bool ok = kk + u < kk1 && !(odd_tail && half == 1 && kk + u == ksteps - 1);
@@ -121,10 +123,6 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
           s2 = fmaf(d, d, s2);
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc, 0, 0, 0);
-      }
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < RG_U; ++u) { fa[u] = na[u]; fb[u] = nbf[u]; }
       }
     }
   }
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
   }
   if (ncol >= a.ncols) return;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (i >= nr) break;
     const int r = ks + i * ksplit;
     const int mr = mb + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
 // Returns -1 when the shape is not one this kernel takes.
 int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   if (a.K != 1 || a.stride != 1 || a.pad != 0 || a.prologue != HSP_PRO_NONE || a.rows != HSP_ROWS_PLAIN) return -1;
-  if (a.x_ts != 1 || a.Lin != a.ncols || a.Lout != a.ncols || a.split_row) return -1;
+  if (a.x_ts < 1 || a.Lin != a.ncols || a.Lout != a.ncols || a.split_row) return -1;   // any column stride of x
   if (a.Cin < 32 || a.Cin > 8192) return -1;
   if (a.ln_c1 && !(a.ln_eps > 0.0f)) return -1;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return -1;
@@ -186,14 +184,13 @@ int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // prologue), 14 against 29 us at K = 1104 -- and a tie around 1 600 x 828; beyond that the LDS kernel's operand
   // reuse wins (3 200 columns: 34-49 us against 43-52), so larger launches stay there.
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.ncols + bn - 1) / bn) * a.B; };
-  const bool forced = RG_DBG(a, 4 | 8 | 16);
-  if (!forced && (int64_t)a.M * a.ncols * a.B > 1400000) return -1;
-  // tile: the largest of 64 x 64 / 64 x 32 / 32 x 32 that still fills the chip
+  const bool forced = RG_DBG(a, 8 | 16);
+  const int64_t outs = (int64_t)a.M * a.ncols * a.B;
+  if (!forced && a.x_ts == 1 && (outs > 1400000 || outs * a.Cin > 500000000)) return -1;
+  // tile: 64 x 32 where that still fills the chip, else 32 x 32 (a 64 x 64 / K-split-2 form was measured and lost)
   int nbm = 1, nbn = 1;
-  if (tiles(64, 64) >= 400) { nbm = 2; nbn = 2; }
-  else if (tiles(64, 32) >= 200) { nbm = 2; nbn = 1; }
+  if (tiles(64, 32) >= 200) { nbm = 2; nbn = 1; }
 #ifdef HSP_TUNING
-  if (a.debug & 4) { nbm = 2; nbn = 2; }
   if (a.debug & 8) { nbm = 2; nbn = 1; }
   if (a.debug & 16) { nbm = 1; nbn = 1; }
 #endif
@@ -204,6 +201,7 @@ int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     plan_out[0] = 32 * nbm; plan_out[1] = 32 * nbn; plan_out[2] = 0; plan_out[3] = (int32_t)(sizeof(float) * (RG_WAVES * 16 * 64 + RG_WAVES * 64));
     return 0;
   }
-  hipLaunchKernelGGL(rgemm_kernel, dim3((unsigned)blocks), dim3(64 * RG_WAVES), 0, s, a, n_mt, n_nt, nbm, nbn);
+  if (a.Cin > 512) hipLaunchKernelGGL(rgemm_kernel<36>, dim3((unsigned)blocks), dim3(64 * RG_WAVES), 0, s, a, n_mt, n_nt, nbm, nbn);
+  else hipLaunchKernelGGL(rgemm_kernel<18>, dim3((unsigned)blocks), dim3(64 * RG_WAVES), 0, s, a, n_mt, n_nt, nbm, nbn);
   return (int)hipGetLastError();
 }
