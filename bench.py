@@ -254,16 +254,22 @@ def vocoder_roofline(args, wl, result):
     from megatts2_hierspeechpp_amd import hip_layers
     # launches must run back to back on one stream here: with the AMP chains / batch groups on
     # side streams the event-bracketed durations of concurrent kernels would overlap
-    saved = (hss.AMP_STREAMS, hss.FRONT_SPLITS)
-    hss.AMP_STREAMS, hss.FRONT_SPLITS = 0, 1
+    # (round 3) exactly the launches of the timed step -- four front groups, the same tile-count policy for the fused
+    # WN / FFN entry points -- only issued serially
+    saved = hss.SERIAL_STREAMS
+    hss.SERIAL_STREAMS = True
     rec, act_rec = [], []
 
+    tiles = {}
+
     def hook(kind, fl, nb, e0, e1, la):
-        # two kernels sit behind hsp_conv1d_mfma_f32: ask the library which one this launch took
+        # three kernels sit behind hsp_conv1d_mfma_f32: ask the library which one this launch took
         if kind == "hsp_conv1d_mfma_f32":
             plan = (C.c_int32 * 4)()
             L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
-            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else "hsp_conv1d_mfma_f32/tokgemm"
+            tiles[len(rec)] = f"{plan[0]}x{plan[1]}"
+            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else ("hsp_conv1d_mfma_f32/tokgemm" if plan[2] == 0
+                                                              else "hsp_conv1d_mfma_f32/rgemm")
         rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
 
     Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
@@ -274,9 +280,10 @@ def vocoder_roofline(args, wl, result):
     finally:
         hip_layers.LAUNCH_HOOK = None
         Fh.ACT_HOOK = None
-        hss.AMP_STREAMS, hss.FRONT_SPLITS = saved
+        hss.SERIAL_STREAMS = saved
     mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
-    tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32/tokgemm"]
+    tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec
+          if kind in ("hsp_conv1d_mfma_f32/tokgemm", "hsp_conv1d_mfma_f32/rgemm")]
     if args.dump_launches:
         agg = {}
         for kind, fl, nb, e0, e1, shp in rec:
@@ -292,14 +299,25 @@ def vocoder_roofline(args, wl, result):
     tot_fl = sum(f for f, _, _ in mf)
     tot_b = sum(b for _, b, _ in mf)
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    # the same launches by tile shape: the Generator's long-sequence convs (128x128, 64x256, 32x512) against the
+    # short-sequence shapes of the four 8-utterance front groups (64x64, 64x128-gated, 32x128)
+    by_tile = {}
+    for i, (kind, fl, nb, e0, e1, _) in enumerate(rec):
+        if kind == "hsp_conv1d_mfma_f32":
+            t = by_tile.setdefault(tiles.get(i, "?"), [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += fl
+            t[2] += e0.elapsed_time(e1)
+    by_tile = {k: {"launches": n, "gflop": f / 1e9, "ms": m, "tflops": f / (m * 1e-3) / 1e12,
+                   "frac": f / (m * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS} for k, (n, f, m) in sorted(by_tile.items())}
 
     # HBM bytes of the same kernel from the PMC counters: measured by tools/pmc_traffic.sh (rocprofv3 cannot wrap
     # a run from inside) and committed under profiles/.  Quoted only when that profile was taken on THIS build of
     # the library, with this workload and this launch mix; otherwise null, with the reason.
     traffic, traffic_note, tj = None, None, None
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if not os.path.exists(path):
-        traffic_note = "no profiles/r02_traffic.json"
+        traffic_note = "no profiles/r03_traffic.json"
     else:
         with open(path) as fh:
             tj = json.load(fh)
@@ -315,16 +333,17 @@ def vocoder_roofline(args, wl, result):
                             "factor calibrated on a float4 copy of known size; raw / x2 / calibrated per step: "
                             + json.dumps(tj["conv1d_mfma_bytes_per_step"]))
     result["roofline"] = {
-        "kernel": "conv1d_mfma_kernel (all tile shapes; the 1x1 token-GEMM launches of the same entry point "
-                  "are excluded: %d launches, %.2f ms per step)" % (len(tg), sum(m for _, _, m in tg)),
+        "kernel": "conv1d_mfma_kernel (every tile shape the timed step launches; the 1x1 token-GEMM launches of the same "
+                  "entry point -- rgemm_kernel / tokgemm_kernel -- are excluded: %d launches, %.2f ms per step)"
+                  % (len(tg), sum(m for _, _, m in tg)),
         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
         "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
         "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
         "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,
         "hbm_frac_of_8TBs": (tot_b / (tot_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
-        "share_of_step_time_single_stream": tot_ms / result["ms_per_step"],
-        "timing": "one extra step, launches serialised on one stream, event pair per launch",
+        "share_of_step_time_single_stream": tot_ms / result["ms_per_step"], "by_tile_shape": by_tile,
+        "timing": "one extra step, the timed step's own launches serialised on one stream, event pair per launch",
     }
     # whole-step fractions SURVEY.md 8(d) defines (Generator-only algorithmic work per audio-second over the step time)
     audio_s = args.batch * args.seconds

@@ -164,7 +164,7 @@ int hsp_conv1d_mfma_f32(const hsp_conv1d_args* a, void* stream);
  * rows must be PLAIN; prologue NONE/LRELU/SILU. */
 int hsp_conv1d_direct_f32(const hsp_conv1d_args* a, void* stream);
 /* which kernel / tile configuration hsp_conv1d_mfma_f32 would pick: writes BM, BN, KC, LDS bytes
- * (KC = 0: the token-GEMM kernel) */
+ * (KC > 0: the conv kernel's chunk depth; KC = 0: the LDS-DMA token GEMM; KC = -1: the register-path token GEMM) */
 int hsp_conv1d_mfma_plan(const hsp_conv1d_args* a, int32_t out4[4]);
 
 /* --------------------------------------- feature producer of inference_vc.py */

@@ -197,8 +197,8 @@ int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   const int n_mt = (a.M + 32 * nbm - 1) / (32 * nbm), n_nt = (a.ncols + 32 * nbn - 1) / (32 * nbn);
   const int64_t blocks = (int64_t)n_mt * n_nt * a.B;
   if (blocks <= 0 || blocks > 0x7fffffff) return -1;
-  if (plan_out) {  // {BM, BN, 0 = "token GEMM", LDS bytes}
-    plan_out[0] = 32 * nbm; plan_out[1] = 32 * nbn; plan_out[2] = 0; plan_out[3] = (int32_t)(sizeof(float) * (RG_WAVES * 16 * 64 + RG_WAVES * 64));
+  if (plan_out) {  // {BM, BN, -1 = "register-path token GEMM" (0 = the LDS-DMA one, > 0 = the conv kernel's chunk depth), LDS bytes}
+    plan_out[0] = 32 * nbm; plan_out[1] = 32 * nbn; plan_out[2] = -1; plan_out[3] = (int32_t)(sizeof(float) * (RG_WAVES * 16 * 64 + RG_WAVES * 64));
     return 0;
   }
   if (a.Cin > 512) hipLaunchKernelGGL(rgemm_kernel<36>, dim3((unsigned)blocks), dim3(64 * RG_WAVES), 0, s, a, n_mt, n_nt, nbm, nbn);

@@ -160,6 +160,10 @@ class AMPBlock1(nn.Module):
 # so the sum is formed in the reference's order ((b0 + b1) + b2) / 3.
 AMP_STREAMS = int(os.environ.get("HSP_AMP_STREAMS", "1"))
 FRONT_SPLITS = int(os.environ.get("HSP_FRONT_SPLITS", "4"))
+# measurement mode (bench.py's per-launch pass, tools/pmc_traffic.sh): the SAME launches as the product step -- the front
+# part still cut into FRONT_SPLITS batch groups, the AMP chains unchanged -- but issued one after the other on the
+# current stream, so that an event pair or a profiler row brackets one kernel alone
+SERIAL_STREAMS = os.environ.get("HSP_SERIAL_STREAMS", "0") == "1"
 _SIDE_STREAMS = {}
 
 
@@ -173,7 +177,7 @@ def _side_streams(device, n):
 
 def _amp_stage(resblocks, first, num_kernels, x):
     """xs = sum_j block_j(x); x = xs / num_kernels (hierspeechpp_speechsynthesizer.py:440-446)."""
-    if not AMP_STREAMS or num_kernels == 1:
+    if not AMP_STREAMS or SERIAL_STREAMS or num_kernels == 1:
         xs = None
         for j in range(num_kernels):
             last = j == num_kernels - 1
@@ -346,7 +350,7 @@ class SynthesizerTrn(nn.Module):
         if noise is None:
             noise = torch.randn(B, self.inter_channels, w2v.shape[2], dtype=torch.float32, device=w2v.device)
         main = torch.cuda.current_stream(w2v.device)
-        side = _side_streams(w2v.device, n - 1)
+        side = [main] * (n - 1) if SERIAL_STREAMS else _side_streams(w2v.device, n - 1)
         fork = torch.cuda.Event()
         fork.record(main)
         z = torch.empty(B, self.inter_channels, w2v.shape[2], dtype=torch.float32, device=w2v.device)
@@ -355,13 +359,13 @@ class SynthesizerTrn(nn.Module):
             lo, hi = bounds[i], bounds[i + 1]
             st = main if i == 0 else side[i - 1]
             with torch.cuda.stream(st):
-                if i > 0:
+                if i > 0 and st is not main:
                     st.wait_event(fork)
                 zi = self._prior(w2v[lo:hi], f0[lo:hi], y_mask[lo:hi], g[lo:hi], noise[lo:hi], noise_scale)
                 zi = self.flow_l(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True)
                 zi = self.flow(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True)
                 z[lo:hi].copy_(zi)
-                if i > 0:
+                if i > 0 and st is not main:
                     ev = torch.cuda.Event()
                     ev.record(st)
                     main.wait_event(ev)

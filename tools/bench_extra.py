@@ -54,18 +54,18 @@ def conv_entry_profile(fn):
         if kind == "hsp_conv1d_mfma_f32":
             plan = (C.c_int32 * 4)()
             L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
-            kind = "conv1d_mfma_kernel" if plan[2] > 0 else "tokgemm_kernel"
+            kind = "conv1d_mfma_kernel" if plan[2] > 0 else ("tokgemm_kernel" if plan[2] == 0 else "rgemm_kernel")
         rec.append((kind, fl, nb, e0, e1))
 
-    saved = (hss.AMP_STREAMS, hss.FRONT_SPLITS)
-    hss.AMP_STREAMS, hss.FRONT_SPLITS = 0, 1
+    saved = hss.SERIAL_STREAMS
+    hss.SERIAL_STREAMS = True          # the product's own launches, one after the other
     hip_layers.LAUNCH_HOOK = hook
     try:
         fn()
         torch.cuda.synchronize()
     finally:
         hip_layers.LAUNCH_HOOK = None
-        hss.AMP_STREAMS, hss.FRONT_SPLITS = saved
+        hss.SERIAL_STREAMS = saved
     agg = {}
     for kind, fl, nb, e0, e1 in rec:
         n, f, b, m = agg.get(kind, (0, 0, 0, 0.0))

@@ -2,7 +2,7 @@
 # visible to --kernel-trace, and concurrent streams would overlap the per-kernel durations).  Run on the GPU box.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export HSP_AMP_STREAMS=0 HSP_FRONT_SPLITS=1
+export HSP_SERIAL_STREAMS=1   # the product step's own launches, one after the other on one stream
 rm -rf $R/gpurun_out/prof_final
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python3 $R/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extra > $R/gpurun_out/prof_final.log 2>&1
 grep '^{' $R/gpurun_out/prof_final.log | tail -1 > $R/gpurun_out/prof_final_bench.json
