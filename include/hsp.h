@@ -18,6 +18,17 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream)
  *   - thread-compatible: the only global state is a per-device "dynamic LDS limit raised" flag per kernel
  *     (atomic, idempotent); the first launch of a kernel on a device must not happen inside a stream capture
+ *
+ * Limits a caller can reach (each is checked: the entry point returns HSP_EINVAL, it never computes garbage)
+ *   - first launch outside a capture: run one eager pass of a model before capturing it into a hipGraph (the
+ *     dynamic-LDS limit of a kernel is raised with hipFuncSetAttribute on its first launch per device)
+ *   - hsp_conv1d_mfma_f32: stride 1; halo (K - 1) * dil + 3 <= 125 columns (plain and gated rows); one utterance of
+ *     a tensor and the packed weight each below 2^31 elements
+ *   - hsp_mha_f32: no sequence-length ceiling (score rows that do not fit LDS are walked in key blocks); head dim
+ *     <= 128 without a relative-position window, <= 256 with one
+ *   - hsp_lstm_bidir_f32: hidden size H <= 256 (one workgroup of 4 H <= 1024 threads holds the gate rows)
+ *   - hsp_wn_layer_f32 / hsp_ffn_conv_f32: one launch for H = 192-class layers (hsp_fused_pair_supported says
+ *     which), layer by layer behind the same entry point otherwise
  */
 #ifndef HSP_H_
 #define HSP_H_
@@ -325,6 +336,7 @@ int hsp_embedding_sum_f32(const int64_t* id0, const int64_t* id1, const int64_t*
  * bhh[dir][4H]; utterance b runs lengths[b] steps (the reverse direction from its own last step, as a
  * packed sequence does) and writes zeros after; out[b, dir*H + j, t] with strides (o_bs, o_cs, 1).
  * nn.LSTM of DurationPredictor (ttv_v1/vits_models.py:101,125) and RangePredictor (ttv_v1/Gaussian.py:100-110). */
+/* Limit: H <= 256 (4 H gate rows = the threads of one workgroup); larger returns HSP_EINVAL. */
 int hsp_lstm_bidir_f32(const float* xproj, int64_t xp_bs, const float* whh_t, const float* bhh,
                        const int64_t* lengths, float* out, int64_t o_bs, int64_t o_cs, int32_t B, int32_t H,
                        int32_t N, void* stream);

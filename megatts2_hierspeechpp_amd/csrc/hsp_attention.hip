@@ -650,13 +650,14 @@ int mha_stream_launch(const hsp_mha_args& a, hipStream_t stream) {
 // LDS = 32 x (Tk + pad) scores + the partial-sum buffer: 45 KB at Tk = 256 -> three workgroups per CU.
 constexpr int TQT = 32;
 
-template <int NDB>
-__global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int n_qt, int sp) {
+template <int NDB, int NW>
+__global__ __launch_bounds__(64 * NW) void mha_tok_kernel(const hsp_mha_args a, int n_qt, int sp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KH = NW / NDB >= 2 ? 2 : 1;          // key halves in the PV phase (8 waves: 2, 4 waves: 1)
   const int D = a.D, Tq = a.Tq, Tk = a.Tk;
   float* S = lds;                        // [32][sp]
-  float* red = S + 32 * sp;              // [NDB][16][64] partial O of the second key half
-  float* inv_s = red + NDB * 16 * 64;    // [32]
+  float* red = S + 32 * sp;              // [NDB][16][64] partial O of the second key half (KH == 2)
+  float* inv_s = red + (KH == 2 ? NDB * 16 * 64 : 0);    // [32]
   int bid = blockIdx.x;
   const int qt = bid % n_qt;
   bid /= n_qt;
@@ -673,15 +674,15 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
   float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
   const int nkb = (Tk + 31) >> 5;
 
-  // ---- scores.  Tk <= 256 = eight key blocks = one per wave, so nothing is reused across blocks: both fragments
-  // are loaded per group of 8 k-steps, the next group in flight under this group's MFMAs (the loop of
+  // ---- scores.  Tk <= 256 = eight key blocks = one (two) per wave, so nothing is reused across blocks: both
+  // fragments are loaded per group of U k-steps, all of a group's loads in flight together (the loop of
   // hsp_rgemm.hip).  Only ceil(D / 2) k-steps run (35 of the padded 48 at D = 69).
   {
     constexpr int U = 18;                             // 35 k-steps at D = 69: two round trips (48 at D = 96: three)
     const int ksteps = (D + 1) >> 1;
     const bool odd_tail = (D & 1) != 0;
     const int iq = min(i0 + l32, Tq - 1);
-    for (int jb = wave; jb < nkb; jb += 8) {
+    for (int jb = wave; jb < nkb; jb += NW) {
       const int j = jb * 32 + l32;
       const float* qp = qh + iq + (int64_t)half * qcs;
       const float* kp = kh + min(j, Tk - 1) + (int64_t)half * kcs;
@@ -711,32 +712,33 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
     }
   }
   __syncthreads();
-  // ---- V fragments: requested NOW, ahead of the softmax they do not depend on (one exposed round trip less).
-  // O^T[d][q] = sum_j V[d][j] P[q][j]: wave = (head-dim block, key half); groups of 8 keys, ALL of a wave's fragments
-  // (<= 16 groups at Tk <= 256) in flight at once.
+  // ---- V fragments of the first chunk: requested NOW, ahead of the softmax they do not depend on.
+  // O^T[d][q] = sum_j V[d][j] P[q][j]: wave = (head-dim block, key part); groups of 8 keys, MAXG groups in flight.
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int MAXG = 16;
-  const int db = wave % NDB, kh2 = wave / NDB;        // waves >= 2 NDB idle in the PV phase
+  const int db = wave % NDB, kh2 = wave / NDB;        // waves >= KH NDB idle in the PV phase
   const int ngrp = (Tk + 7) >> 3;                     // groups of 8 keys
-  const int g0 = kh2 == 0 ? 0 : (ngrp + 1) / 2, g1 = kh2 >= 2 ? 0 : (kh2 == 0 ? (ngrp + 1) / 2 : ngrp);
+  const int gsplit = KH == 2 ? (ngrp + 1) / 2 : ngrp;
+  const int g0 = kh2 == 0 ? 0 : gsplit, g1 = kh2 >= KH ? 0 : (kh2 == 0 ? gsplit : ngrp);
   const int dv = db * 32 + l32;
   const bool dok = dv < D;
+  const float* vrow = vh + (int64_t)min(dv, D - 1) * vcs;
   // lane (d, half) wants V[d][jl .. jl + 3], jl = 8 g + 4 half: one 16-B load (4-B aligned: the utterances of a
   // batch sit side by side on the column axis).  A window that would end beyond Tk (last group only) is moved
   // back inside the row -- Tk >= 4 here -- and re-indexed below; what lies beyond Tk is zero.
   f4u v[MAXG];
-  {
-    const float* vrow = vh + (int64_t)min(dv, D - 1) * vcs;
+  auto vload = [&](int gb) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < MAXG; ++u) {
-      const int jl = 8 * (g0 + u) + 4 * half;
-      if (g0 + u < g1) v[u] = *reinterpret_cast<const f4u*>(vrow + max(min(jl, Tk - 4), 0));
+      const int jl = 8 * (gb + u) + 4 * half;
+      if (gb + u < g1) v[u] = *reinterpret_cast<const f4u*>(vrow + max(min(jl, Tk - 4), 0));
     }
-  }
-  // ---- row softmax, 4 rows per wave; P is left un-normalised, 1 / sum goes to the output
+  };
+  vload(g0);
+  // ---- row softmax, 32 / NW rows per wave; P is left un-normalised, 1 / sum goes to the output
   const int ncol = nkb * 32;                          // columns written above (the padding holds -3e38 -> 0)
-  for (int u = 0; u < 4; ++u) {
-    const int row_i = wave * 4 + u;
+  for (int u = 0; u < 32 / NW; ++u) {
+    const int row_i = wave * (32 / NW) + u;
     float* row = S + row_i * sp;
     float mx = -3.0e38f;
     for (int j = lane; j < ncol; j += 64) mx = fmaxf(mx, row[j]);
@@ -756,62 +758,74 @@ __global__ __launch_bounds__(512) void mha_tok_kernel(const hsp_mha_args a, int 
   // zero the columns [ncol, ncol8) the PV groups of eight keys may read
   {
     const int ncol8 = (ncol + 7) & ~7;
-    for (int e = tid; e < 32 * (ncol8 - ncol); e += 512) S[(e / (ncol8 - ncol)) * sp + ncol + e % (ncol8 - ncol)] = 0.0f;
+    for (int e = tid; e < 32 * (ncol8 - ncol); e += 64 * NW) S[(e / (ncol8 - ncol)) * sp + ncol + e % (ncol8 - ncol)] = 0.0f;
   }
   __syncthreads();
-  // ---- O^T += V P^T on the fragments requested above
+  // ---- O^T += V P^T
   mha_f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
-  if (kh2 < 2) {
+  if (kh2 < KH) {
     const float* prow = S + l32 * sp + 4 * half;
+    for (int gb = g0; gb < g1; gb += MAXG) {
+      if (gb > g0) vload(gb);
 #pragma unroll
-    for (int u = 0; u < MAXG; ++u) {
-      if (g0 + u < g1) {
-        const int jl = 8 * (g0 + u) + 4 * half;
-        const int sh = jl - max(min(jl, Tk - 4), 0);  // 0 except in the last group
-        float v4[4];
+      for (int u = 0; u < MAXG; ++u) {
+        if (gb + u < g1) {
+          const int jl = 8 * (gb + u) + 4 * half;
+          const int sh = jl - max(min(jl, Tk - 4), 0);  // 0 except in the last group
+          float v4[4];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const int idx = qq + sh;                    // position of key jl + qq inside the loaded window
-          const float val = idx == 0 ? v[u][0] : idx == 1 ? v[u][1] : idx == 2 ? v[u][2] : idx == 3 ? v[u][3] : 0.0f;
-          v4[qq] = dok ? val : 0.0f;
+          for (int qq = 0; qq < 4; ++qq) {
+            const int idx = qq + sh;                    // position of key jl + qq inside the loaded window
+            const float val = idx == 0 ? v[u][0] : idx == 1 ? v[u][1] : idx == 2 ? v[u][2] : idx == 3 ? v[u][3] : 0.0f;
+            v4[qq] = dok ? val : 0.0f;
+          }
+          const float* pp = prow + 8 * (gb + u);
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[qq], pp[qq], oacc, 0, 0, 0);
         }
-        const float* pp = prow + 8 * (g0 + u);
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[qq], pp[qq], oacc, 0, 0, 0);
       }
     }
-    if (kh2 == 1) {
+    if (KH == 2 && kh2 == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(db * 16 + r) * 64 + lane] = oacc[r];
     }
   }
-  __syncthreads();
+  if (KH == 2) __syncthreads();
   if (kh2 == 0 && i0 + l32 < Tq) {
     const float inv = inv_s[l32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = (oacc[r] + red[(db * 16 + r) * 64 + lane]) * inv;
+      if (d < D) oh[(int64_t)d * ocs + i0 + l32] = (oacc[r] + (KH == 2 ? red[(db * 16 + r) * 64 + lane] : 0.0f)) * inv;
     }
   }
 }
 
-template <int NDB>
-int mha_tok_launch(const hsp_mha_args& a, hipStream_t stream) {
+template <int NDB, int NW>
+int mha_tok_launch_nw(const hsp_mha_args& a, hipStream_t stream, int64_t blocks, int n_qt) {
+  constexpr int KH = NW / NDB >= 2 ? 2 : 1;
   const int nkb = (a.Tk + 31) >> 5;
   const int sp = ((nkb * 32 + 7) & ~7) + 1;
-  const size_t lds_bytes = ((size_t)32 * sp + NDB * 16 * 64 + 32) * sizeof(float);
-  const int n_qt = (a.Tq + TQT - 1) / TQT;
-  const int64_t blocks = (int64_t)n_qt * a.H * a.B;
-  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
+  const size_t lds_bytes = ((size_t)32 * sp + (KH == 2 ? NDB * 16 * 64 : 0) + 32) * sizeof(float);
   static hsp_lds_flags flags;   // raised ONCE per device, so to the kernel's maximum (Tk = 256), not to this launch's size
   constexpr int kMaxLds = (32 * 265 + NDB * 16 * 64 + 32) * (int)sizeof(float);
   if (lds_bytes > 32 * 1024)
-    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_tok_kernel<NDB>), kMaxLds, flags)) return e;
-  hipLaunchKernelGGL((mha_tok_kernel<NDB>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, a, n_qt, sp);
+    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(mha_tok_kernel<NDB, NW>), kMaxLds, flags)) return e;
+  hipLaunchKernelGGL((mha_tok_kernel<NDB, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds_bytes, stream, a, n_qt, sp);
   return (int)hipGetLastError();
+}
+
+template <int NDB>
+int mha_tok_launch(const hsp_mha_args& a, hipStream_t stream) {
+  const int n_qt = (a.Tq + TQT - 1) / TQT;
+  const int64_t blocks = (int64_t)n_qt * a.H * a.B;
+  if (blocks <= 0 || blocks > 0x7fffffff) return HSP_EINVAL;
+  // eight waves: one key block each, two key halves in the PV phase.  (A four-wave form, of which a CU holds more,
+  // was measured on 448 / 896 workgroups: 38.7 / 53.5 us against 32.6 / 58.1 -- its per-workgroup chain is twice as
+  // long -- and is not built.)
+  return mha_tok_launch_nw<NDB, 8>(a, stream, blocks, n_qt);
 }
 
 }  // namespace

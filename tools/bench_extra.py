@@ -73,10 +73,34 @@ def conv_entry_profile(fn):
     return agg
 
 
-def dominant_roofline(agg):
+def _pmc_traffic(workload, kind, launches):
+    """HBM bytes per launch of `kind` from the committed PMC profile of this workload's dominant stage
+    (profiles/r03_traffic_extra.json, tools/pmc_traffic_extra.sh), or (None, reason)."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r03_traffic_extra.json")
+    if workload is None or not os.path.exists(path):
+        return None, "no profiles/r03_traffic_extra.json"
+    from megatts2_hierspeechpp_amd.build import source_id
+    tj = json.load(open(path))
+    if tj.get("kernel_source_sha16") != source_id():
+        return None, f"profile taken on kernel sources {tj.get('kernel_source_sha16')}, this run uses {source_id()}"
+    k = tj.get(workload, {}).get(kind)
+    if not k:
+        return None, f"no {kind} in the profile"
+    if k["launches"] != launches:
+        return None, f"profile has {k['launches']} launches of {kind}, this run {launches}"
+    f16 = 1.94     # FETCH_SIZE under-reports 16-B-per-lane streams (r03_traffic.json calibrates 1.94 on the activation kernel)
+    fac = 1.0 / 0.90 if kind == "rgemm_kernel" else f16
+    total = 1024.0 * (fac * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"])
+    return total / launches, (f"PMC FETCH_SIZE x {fac:.2f} + WRITE_SIZE per launch; raw FETCH {k['FETCH_SIZE_KB'] * 1024 / launches:.0f} B, "
+                              f"WRITE {k['WRITE_SIZE_KB'] * 1024 / launches:.0f} B")
+
+
+def dominant_roofline(agg, workload=None):
     if not agg:
         return None
     kind, (n, fl, nb, ms) = max(agg.items(), key=lambda kv: kv[1][3])
+    traffic, tnote = _pmc_traffic(workload, kind, n)
     tf = fl / (ms * 1e-3) / 1e12
     gbs = nb / (ms * 1e-3) / 1e9
     mfma_frac, hbm_frac = tf / FP32_MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
@@ -85,7 +109,8 @@ def dominant_roofline(agg):
             "achieved": tf if bound == "mfma" else gbs, "peak": FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(mfma_frac, hbm_frac),
             "mfma_frac": mfma_frac, "hbm_frac": hbm_frac, "launches_per_step": n, "kernel_ms_per_step": ms,
-            "algorithmic_gflop_per_step": fl / 1e9, "algorithmic_mb_per_step": nb / 1e6, "traffic": None,
+            "algorithmic_gflop_per_step": fl / 1e9, "algorithmic_mb_per_step": nb / 1e6,
+            "algorithmic_bytes_per_launch": nb / n, "traffic": traffic, "traffic_note": tnote,
             "timing": "one extra eager step on one stream, event pair per launch"}
 
 
@@ -160,7 +185,10 @@ def tts_b16(dev, steps=3, warmup=1, batch=16, phones=40, use_graph=True, models=
     torch.cuda.synchronize()
     names = ["front_end(A16-A17)", "plm_loop(A18)", "w2v+pitch(A17)", "vocoder(A1-A14)", "int16_post(A19)"]
     stages = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
-    roof = dominant_roofline(conv_entry_profile(lambda: step(None, eager=True)))
+    roof = dominant_roofline(conv_entry_profile(lambda: models.plm.infer(plm_graph["x"]) if "x" in plm_graph
+                                                else step(None, eager=True)), "tts")
+    if roof:
+        roof["scope"] = "the PLM greedy loop (the dominant stage of this config), all launches behind the conv entry point"
     return {"metric": "16kHz audio samples/sec, full inference_plm.py text->wav, batch=16 (BASELINE.json configs[2])",
             "value": B * 320 * T2 / el, "unit": "samples/s", "ms_per_step": el * 1e3,
             "rtf": el / (B * 320 * T2 / 16000.0), "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
@@ -246,7 +274,7 @@ def sr48_b32(dev, steps=5, batch=32, net=None):
     e[2].record()
     torch.cuda.synchronize()
     assert o48.shape == (B, 1, 3 * 320 * T) and bool(torch.isfinite(o48).all())
-    roof = dominant_roofline(conv_entry_profile(lambda: sr(o)))
+    roof = dominant_roofline(conv_entry_profile(lambda: sr(o)), "sr48")
     if roof:
         roof["scope"] = "SpeechSR48 stage only (the vocoder stage is the headline's roofline)"
     return {"metric": "48 kHz samples/s, vocoder + SpeechSR48, batch=32 (BASELINE.json configs[3])",
