@@ -611,6 +611,29 @@ def test_attention_key_streaming_kernels(B, H, D, Tq, Tk, window, masked, device
         _close(got.cpu().numpy(), want.numpy(), "default dispatch at a length beyond LDS")
 
 
+@pytest.mark.parametrize("B,H,D,Tq,Tk", [(2, 4, 69, 4, 4), (1, 4, 69, 5, 5), (3, 2, 96, 31, 31), (2, 4, 20, 33, 33),
+                                          (1, 2, 64, 200, 200), (2, 4, 69, 255, 255), (1, 1, 96, 256, 256), (2, 3, 32, 7, 101),
+                                          (1, 4, 69, 1, 130), (2, 2, 96, 3, 3)])
+def test_maskless_short_sequence_attention_vs_torch(B, H, D, Tq, Tk, device):
+    """The latency-oriented kernel (no masks, 4 <= Tk <= 256, head dim <= 96: the PLM prefix, timm Attention of the DiT
+    blocks) at its boundaries -- key counts around the 32-key block and the 8-key PV group, one query, Tq != Tk, head
+    dims that are no multiple of 32 -- and the whole-row kernel below four keys, against torch."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    g = torch.Generator().manual_seed(D * 1000 + Tk)
+    q = torch.randn(B, H * D, Tq, generator=g)
+    k, v = torch.randn(B, H * D, Tk, generator=g), torch.randn(B, H * D, Tk, generator=g)
+    want = _torch_attention(q, k, v, H, D ** -0.5)
+    got = Fh.mha(q.to(device), k.to(device), v.to(device), H, D ** -0.5)
+    _close(got.cpu().numpy(), want.numpy(), f"D={D} Tq={Tq} Tk={Tk}")
+    # the PLM layout: the batch side by side on the column axis of one [C, B * T] matrix (4-B aligned rows only)
+    if Tq == Tk:
+        cat = lambda t: t.permute(1, 0, 2).reshape(H * D, B * Tk).contiguous().to(device)
+        per = lambda m: m.reshape(H * D, B, Tk).permute(1, 0, 2)
+        o = torch.empty(H * D, B * Tk, device=device)
+        Fh.mha(per(cat(q)), per(cat(k)), per(cat(v)), H, D ** -0.5, out=per(o))
+        _close(per(o).cpu().numpy(), want.numpy(), "strided batch layout")
+
+
 def test_long_prompts_have_no_attention_ceiling(device):
     """A 60-s prompt mel through the StyleEncoder (3 000 frames, ragged pair) and the denoiser's conformer block with
     3 200 frames on its attention axis (a 20-s prompt: denoiser/conformer.py:45-60 runs nn.MultiheadAttention along
