@@ -673,12 +673,20 @@ __global__ __launch_bounds__(64 * NW) void mha_tok_kernel(const hsp_mha_args a, 
   const float* vh = a.v + (int64_t)b * a.v_bs + (int64_t)h * D * vcs;
   float* oh = a.o + (int64_t)b * a.o_bs + (int64_t)h * D * ocs;
   const int nkb = (Tk + 31) >> 5;
+#ifdef HSP_TUNING
+  unsigned long long* stamps = (a.window == 1003 && blockIdx.x == 0 && tid == 0) ? (unsigned long long*)a.rel_v : nullptr;
+#define MT_STAMP(i) do { if (stamps) stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MT_STAMP(i) do { } while (0)
+#endif
+  MT_STAMP(0);
 
   // ---- scores.  Tk <= 256 = eight key blocks = one (two) per wave, so nothing is reused across blocks: both
   // fragments are loaded per group of U k-steps, all of a group's loads in flight together (the loop of
   // hsp_rgemm.hip).  Only ceil(D / 2) k-steps run (35 of the padded 48 at D = 69).
   {
-    constexpr int U = 18;                             // 35 k-steps at D = 69: two round trips (48 at D = 96: three)
+    constexpr int U = NDB == 3 ? 36 : 32;             // k-steps requested together: all 35 of D = 69 (one round trip; in-kernel stamps:
+                                                      // two groups of 18 cost 4 us of a 9-us launch), 48 at D = 96 in two
     const int ksteps = (D + 1) >> 1;
     const bool odd_tail = (D & 1) != 0;
     const int iq = min(i0 + l32, Tq - 1);
@@ -711,7 +719,9 @@ __global__ __launch_bounds__(64 * NW) void mha_tok_kernel(const hsp_mha_args a, 
       for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * half) * sp + j] = jok ? acc[r] : -3.0e38f;
     }
   }
+  MT_STAMP(1);
   __syncthreads();
+  MT_STAMP(2);
   // ---- V fragments of the first chunk: requested NOW, ahead of the softmax they do not depend on.
   // O^T[d][q] = sum_j V[d][j] P[q][j]: wave = (head-dim block, key part); groups of 8 keys, MAXG groups in flight.
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -735,55 +745,95 @@ __global__ __launch_bounds__(64 * NW) void mha_tok_kernel(const hsp_mha_args a, 
     }
   };
   vload(g0);
-  // ---- row softmax, 32 / NW rows per wave; P is left un-normalised, 1 / sum goes to the output
+  // ---- row softmax, 32 / NW rows per wave, walked in LOCKSTEP: a wave-wide reduction is six dependent cross-lane
+  // steps of ~150 cycles each, and the rows' chains are independent (in-kernel stamps: row after row this phase was
+  // 2.9 us of a 9-us launch at 16 keys).  P is left un-normalised, 1 / sum goes to the output.
   const int ncol = nkb * 32;                          // columns written above (the padding holds -3e38 -> 0)
-  for (int u = 0; u < 32 / NW; ++u) {
-    const int row_i = wave * (32 / NW) + u;
-    float* row = S + row_i * sp;
-    float mx = -3.0e38f;
-    for (int j = lane; j < ncol; j += 64) mx = fmaxf(mx, row[j]);
+  {
+    constexpr int NR = 32 / NW;
+    float* rows[NR];
+    float mx[NR], sum[NR];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sum = 0.0f;
+    for (int u = 0; u < NR; ++u) {
+      rows[u] = S + (wave * NR + u) * sp;
+      mx[u] = -3.0e38f;
+      sum[u] = 0.0f;
+    }
     for (int j = lane; j < ncol; j += 64) {
-      const float sv = row[j];
-      const float e = sv > -1.0e38f ? __builtin_amdgcn_exp2f((sv - mx) * 1.4426950408889634f) : 0.0f;
-      row[j] = e;
-      sum += e;
+#pragma unroll
+      for (int u = 0; u < NR; ++u) mx[u] = fmaxf(mx[u], rows[u][j]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) inv_s[row_i] = 1.0f / sum;
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < NR; ++u) mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], o, 64));
+    }
+    for (int j = lane; j < ncol; j += 64) {
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const float sv = rows[u][j];
+        const float e = sv > -1.0e38f ? __builtin_amdgcn_exp2f((sv - mx[u]) * 1.4426950408889634f) : 0.0f;
+        rows[u][j] = e;
+        sum[u] += e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < NR; ++u) sum[u] += __shfl_xor(sum[u], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < NR; ++u) inv_s[wave * NR + u] = 1.0f / sum[u];
+    }
   }
   // zero the columns [ncol, ncol8) the PV groups of eight keys may read
   {
     const int ncol8 = (ncol + 7) & ~7;
     for (int e = tid; e < 32 * (ncol8 - ncol); e += 64 * NW) S[(e / (ncol8 - ncol)) * sp + ncol + e % (ncol8 - ncol)] = 0.0f;
   }
+  MT_STAMP(3);
   __syncthreads();
+  MT_STAMP(4);
   // ---- O^T += V P^T
   mha_f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
   if (kh2 < KH) {
     const float* prow = S + l32 * sp + 4 * half;
+    const int glast = ngrp - 1;                       // the only group whose window may have been moved back
     for (int gb = g0; gb < g1; gb += MAXG) {
       if (gb > g0) vload(gb);
+      if (!dok) {                                     // head-dim rows beyond D (last block only): contribute nothing
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) v[u] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      float pc[4], pn[4];                             // P fragments of the current / next group
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) pc[qq] = prow[8 * gb + qq];
 #pragma unroll
       for (int u = 0; u < MAXG; ++u) {
         if (gb + u < g1) {
-          const int jl = 8 * (gb + u) + 4 * half;
-          const int sh = jl - max(min(jl, Tk - 4), 0);  // 0 except in the last group
-          float v4[4];
+          if (gb + u + 1 < g1) {
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int idx = qq + sh;                    // position of key jl + qq inside the loaded window
-            const float val = idx == 0 ? v[u][0] : idx == 1 ? v[u][1] : idx == 2 ? v[u][2] : idx == 3 ? v[u][3] : 0.0f;
-            v4[qq] = dok ? val : 0.0f;
+            for (int qq = 0; qq < 4; ++qq) pn[qq] = prow[8 * (gb + u + 1) + qq];
           }
-          const float* pp = prow + 8 * (gb + u);
+          f4u vv = v[u];
+          if (gb + u == glast) {                      // wave-uniform: re-index the moved window, zero what lies beyond Tk
+            const int jl = 8 * (gb + u) + 4 * half;
+            const int sh = jl - max(min(jl, Tk - 4), 0);
+            float t4[4];
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[qq], pp[qq], oacc, 0, 0, 0);
+            for (int qq = 0; qq < 4; ++qq) {
+              const int idx = qq + sh;
+              t4[qq] = idx == 0 ? vv[0] : idx == 1 ? vv[1] : idx == 2 ? vv[2] : idx == 3 ? vv[3] : 0.0f;
+            }
+            vv = f4u{t4[0], t4[1], t4[2], t4[3]};
+          }
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[qq], pc[qq], oacc, 0, 0, 0);
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) pc[qq] = pn[qq];
         }
       }
     }
@@ -792,7 +842,9 @@ __global__ __launch_bounds__(64 * NW) void mha_tok_kernel(const hsp_mha_args a, 
       for (int r = 0; r < 16; ++r) red[(db * 16 + r) * 64 + lane] = oacc[r];
     }
   }
+  MT_STAMP(5);
   if (KH == 2) __syncthreads();
+  MT_STAMP(6);
   if (kh2 == 0 && i0 + l32 < Tq) {
     const float inv = inv_s[l32];
 #pragma unroll
@@ -801,6 +853,8 @@ __global__ __launch_bounds__(64 * NW) void mha_tok_kernel(const hsp_mha_args a, 
       if (d < D) oh[(int64_t)d * ocs + i0 + l32] = (oacc[r] + (KH == 2 ? red[(db * 16 + r) * 64 + lane] : 0.0f)) * inv;
     }
   }
+  MT_STAMP(7);
+#undef MT_STAMP
 }
 
 template <int NDB, int NW>
@@ -843,6 +897,15 @@ extern "C" int hsp_mha_f32(const hsp_mha_args* ap, void* stream) {
   // test hook: window = -(w + 1) selects the key-streaming kernels at any Tk, with window w
   const bool force_stream = a.window < 0;
   if (force_stream) a.window = -(a.window + 1);
+#ifdef HSP_TUNING
+  if (a.window == 1003 && a.rel_v && !a.rel_k) {   // in-kernel phase stamps of workgroup 0 -> rel_v (8 x uint64): tools/mha_stamps.py
+    switch ((a.D + 31) / 32) {
+      case 1: return mha_tok_launch<1>(a, static_cast<hipStream_t>(stream));
+      case 2: return mha_tok_launch<2>(a, static_cast<hipStream_t>(stream));
+      default: return mha_tok_launch<3>(a, static_cast<hipStream_t>(stream));
+    }
+  }
+#endif
   if ((a.rel_k || a.rel_v) && (a.window <= 0 || a.Tq != a.Tk)) return HSP_EINVAL;
   if (a.mask_dense && a.mask_dense_bs < (int64_t)a.Tq * a.Tk) return HSP_EINVAL;
   const hipStream_t st = static_cast<hipStream_t>(stream);
