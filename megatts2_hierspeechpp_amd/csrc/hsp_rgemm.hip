@@ -60,6 +60,15 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
   const int per = (ksteps + ksplit - 1) / ksplit;
   const int kk0 = ks * per, kk1 = min(kk0 + per, ksteps);
 
+#ifdef HSP_TUNING
+  // tuning bit 1 << 20: cycle-counter stamps of workgroup (gridDim.x / 2), wave 0, lane 0 -> a.filt (6 x uint64)
+  unsigned long long* stamps = ((a.debug & (1 << 20)) && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+                                   ? (unsigned long long*)a.filt : nullptr;
+#define RG_STAMP(i) do { if (stamps) stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RG_STAMP(i) do { } while (0)
+#endif
+  RG_STAMP(0);
   // clamped (always legal) fragment addresses: rows >= M / columns >= ncols compute garbage nobody stores
   const int m = min(mb + l32, a.M - 1);
   const int n = min(nb + l32, a.ncols - 1);
@@ -127,6 +136,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
     }
   }
 
+  RG_STAMP(1);
   // ---- K-split exchange through LDS
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
@@ -135,7 +145,9 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
     s2 += __shfl_xor(s2, 32, 64);
     if (half == 0) { stat[wave][0][l32] = s1; stat[wave][1][l32] = s2; }
   }
+  RG_STAMP(2);
   __syncthreads();
+  RG_STAMP(3);
   float mean = 0.0f, rstd = 1.0f;
   if (a.ln_c1) {
     float t1 = 0.0f, t2 = 0.0f;
@@ -167,6 +179,8 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
     v += yv[i];
     yb[(int64_t)mr * a.y_cs] = v * a.post_scale;
   }
+  RG_STAMP(4);
+#undef RG_STAMP
 }
 
 }  // namespace
