@@ -1005,7 +1005,12 @@ int launch_one(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // a shape whose register budget admits two workgroups per CU keeps its LDS under half the
   // CU's; the others take the deepest chunk the whole 160 KB can stage (fewer barriers, and the
   // DMA of a chunk gets a longer MFMA phase to land under)
-  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS;
+  // Round 3: the short-sequence shapes (64 x 64, 64 x 128-gated, 32 x 128: <= 87 VGPRs, one workgroup per CU with the deep
+  // chunk) take the half-CU chunk as well once the launch has more tiles than the chip has CUs: the FFN fc1 of an
+  // 8-utterance front group is 384 tiles -- two rounds of lone workgroups at 52 us, one round of pairs at ~40.
+  const int64_t tiles = (int64_t)((a.M + C::BM - 1) / C::BM) * ((a.ncols + C::BN - 1) / C::BN) * a.B;
+  // (same box: 42.4 -> 39.3 us per launch, step 81.05 -> 80.77 ms; beyond 512 tiles the deep chunk wins again: 67.8 vs 69.7)
+  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS || (tiles > 256 && tiles <= 512 && !HSP_DBG(a, 1 << 21));
   int lkc = pick_lkc<C>(a, two_per_cu ? kLdsTarget : kMaxLdsBytes);
   if (lkc < 0) lkc = pick_lkc<C>(a, kMaxLdsBytes);
   if (lkc < 0) return HSP_EINVAL;
