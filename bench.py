@@ -268,8 +268,8 @@ def vocoder_roofline(args, wl, result):
             plan = (C.c_int32 * 4)()
             L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
             tiles[len(rec)] = f"{plan[0]}x{plan[1]}"
-            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else ("hsp_conv1d_mfma_f32/tokgemm" if plan[2] == 0
-                                                              else "hsp_conv1d_mfma_f32/rgemm")
+            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else ("hsp_conv1d_mfma_f32/tokgemm" if plan[2] == 0 else (
+                "hsp_conv1d_mfma_f32/rgemm" if plan[2] == -1 else "hsp_conv1d_mfma_f32/bgemm"))
         rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
 
     Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
@@ -283,7 +283,7 @@ def vocoder_roofline(args, wl, result):
         hss.SERIAL_STREAMS = saved
     mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
     tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec
-          if kind in ("hsp_conv1d_mfma_f32/tokgemm", "hsp_conv1d_mfma_f32/rgemm")]
+          if kind in ("hsp_conv1d_mfma_f32/tokgemm", "hsp_conv1d_mfma_f32/rgemm", "hsp_conv1d_mfma_f32/bgemm")]
     if args.dump_launches:
         agg = {}
         for kind, fl, nb, e0, e1, shp in rec:

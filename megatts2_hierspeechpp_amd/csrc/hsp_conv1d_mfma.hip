@@ -7,6 +7,7 @@
 
 int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);  // hsp_tokgemm.hip; -1 = shape not taken
 int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);    // hsp_rgemm.hip; likewise
+int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);    // hsp_bgemm.hip; likewise
 
 namespace {
 using namespace hspconv;
@@ -48,6 +49,12 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // 36 us against 67 us at C = 128, k = 7) for a quarter of the work, so the small shape wins up to 64 big tiles,
   // ties up to 128 and loses 2x beyond (tools/conv_sweep.py, profiles/r02_tile_threshold.txt).
   const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B <= 128;
+  // 1x1 GEMMs with enough outputs for about one 128 x 128 / 128 x 64 tile per CU (the PLM loop beyond ~60 prefix
+  // positions): the throughput-oriented token GEMM (hsp_bgemm.hip)
+  if (a.K == 1 && !HSP_DBG(a, 128)) {
+    const int e = hsp_bgemm_try(a, s, plan_out);
+    if (e >= 0) return e;
+  }
   if ((short_seq || a.ln_c1 || a.split_row) && !HSP_DBG(a, 128)) {
     // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip), else the LDS-DMA
     // token GEMM (hsp_tokgemm.hip: second-output launches; tuning bit 131072 forces it for A/B runs)
