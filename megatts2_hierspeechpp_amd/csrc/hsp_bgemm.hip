@@ -173,10 +173,74 @@ __device__ __forceinline__ void bg_epilogue(const hsp_conv1d_args& a, const bg_f
   }
 }
 
+// The same with everything hsp_conv1d_args can ask of a plain-row epilogue (the DiT / WN token GEMMs of the vocoder's
+// 50 Hz part): mask before / after the residual, per-(b, c) scale, scale, running sum, post_scale and the second output
+// of hsp_conv1d_args.split_row (whole 64-row tiles at or beyond split_row write y2 with their own parameter set).
+// Same operation order as hsp_epilogue_store; a factor that is not asked for is an exact multiplication by 1.
+template <int TM, int TN, int ACT>
+__device__ __forceinline__ void bg_epilogue_ext(const hsp_conv1d_args& a, const bg_f32x16 (&acc)[TM * TN], int b, int m0, int mw,
+                                                int nw, int l32, int half, float bvl) {
+  const bool second = a.split_row > 0 && m0 >= a.split_row;
+  const int mo = second ? a.split_row : 0;
+  const int mmode = second ? a.mask_mode2 : a.mask_mode;
+  const bool accum = (second ? a.accumulate2 : a.accumulate) != 0;
+  const int64_t ycs = second ? a.y2_cs : a.y_cs;
+  const char* ybase = reinterpret_cast<const char*>((second ? a.y2 + (int64_t)b * a.y2_bs : a.y + (int64_t)b * a.y_bs) + nw);
+  const char* rbase = (a.res && !second) ? reinterpret_cast<const char*>(a.res + (int64_t)b * a.res_bs + nw) : nullptr;
+  const unsigned yo = 4u * (unsigned)(l32 + 4 * half * (int)ycs), ro = 4u * (unsigned)(l32 + 4 * half * a.res_cs);
+  const float csl = a.cscale ? a.cscale[(int64_t)b * a.cscale_bs + min(mw + l32 + 32 * half, a.Cout - 1)] : 1.0f;
+  const float sc = a.scale, ps = a.post_scale;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    float bvr[16], csr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int src = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      bvr[r] = __shfl(bvl, src, 64);
+      csr[r] = __shfl(csl, src, 64);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = nw + tn * 32 + l32;
+      if (n < a.ncols) {
+        const float mk = mmode != HSP_MASK_NONE ? a.mask[(int64_t)b * a.mask_bs + n] : 1.0f;
+        const float mk_pre = (mmode & HSP_MASK_PRE) ? mk : 1.0f, mk_post = (mmode & HSP_MASK_POST) ? mk : 1.0f;
+        float rv[16], yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mc = min(mw + tm * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1 - 4 * half) - mo;
+          rv[r] = rbase ? *reinterpret_cast<const float*>(rbase + (int64_t)mc * a.res_cs * 4 + tn * 128 + ro) : 0.0f;
+          yv[r] = accum ? *reinterpret_cast<const float*>(ybase + (int64_t)mc * ycs * 4 + tn * 128 + yo) : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mu = mw + tm * 32 + 8 * q;
+          if (mu + 4 * half < a.Cout) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * q + i;
+              float v = acc[tm * TN + tn][r] + bvr[r];
+              if constexpr (ACT == HSP_ACT_RELU) v = fmaxf(v, 0.0f);
+              else if constexpr (ACT == HSP_ACT_GELU_TANH) v = hsp_apply_act(v, HSP_ACT_GELU_TANH);
+              v *= mk_pre;
+              v *= csr[r];
+              v *= sc;
+              v += rv[r];
+              v *= mk_post;
+              v += yv[r];
+              *reinterpret_cast<float*>(const_cast<char*>(ybase) + (int64_t)(mu + i - mo) * ycs * 4 + tn * 128 + yo) = v * ps;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void bg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TM, int TN, bool LN>
+template <int TM, int TN, bool LN, bool EXT>
 __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, int n_mt, int n_nt, int per_xcd,
                                                        int total) {
   using C = BgCfg<TM, TN>;
@@ -338,22 +402,34 @@ __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, 
   }
 
   // ---- epilogue (hsp_bgemm_try admits these three pointwise functions only)
-  if (a.act == HSP_ACT_RELU) bg_epilogue<TM, TN, LN, HSP_ACT_RELU>(a, acc, b, mw, nw, l32, half, bvl, c1l, mean, rstd);
-  else if (a.act == HSP_ACT_GELU_TANH) bg_epilogue<TM, TN, LN, HSP_ACT_GELU_TANH>(a, acc, b, mw, nw, l32, half, bvl, c1l, mean, rstd);
-  else bg_epilogue<TM, TN, LN, HSP_ACT_NONE>(a, acc, b, mw, nw, l32, half, bvl, c1l, mean, rstd);
+  if constexpr (EXT) {
+    static_assert(!LN, "the extended epilogue is not built with the fused LayerNorm");
+    if (a.act == HSP_ACT_RELU) bg_epilogue_ext<TM, TN, HSP_ACT_RELU>(a, acc, b, m0, mw, nw, l32, half, bvl);
+    else if (a.act == HSP_ACT_GELU_TANH) bg_epilogue_ext<TM, TN, HSP_ACT_GELU_TANH>(a, acc, b, m0, mw, nw, l32, half, bvl);
+    else bg_epilogue_ext<TM, TN, HSP_ACT_NONE>(a, acc, b, m0, mw, nw, l32, half, bvl);
+  } else {
+    if (a.act == HSP_ACT_RELU) bg_epilogue<TM, TN, LN, HSP_ACT_RELU>(a, acc, b, mw, nw, l32, half, bvl, c1l, mean, rstd);
+    else if (a.act == HSP_ACT_GELU_TANH) bg_epilogue<TM, TN, LN, HSP_ACT_GELU_TANH>(a, acc, b, mw, nw, l32, half, bvl, c1l, mean, rstd);
+    else bg_epilogue<TM, TN, LN, HSP_ACT_NONE>(a, acc, b, mw, nw, l32, half, bvl, c1l, mean, rstd);
+  }
   BG_STAMP(3);
 #undef BG_STAMP
 }
 
-template <int TM, int TN, bool LN>
+template <int TM, int TN, bool LN, bool EXT>
 int bg_launch(const hsp_conv1d_args& a, hipStream_t s, int n_mt, int n_nt, int total) {
   using C = BgCfg<TM, TN>;
   static hsp_lds_flags flags;
-  if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(bgemm_kernel<TM, TN, LN>), C::LDS_BYTES, flags)) return e;
+  if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(bgemm_kernel<TM, TN, LN, EXT>), C::LDS_BYTES, flags)) return e;
   const int per_xcd = (total + 7) / 8;
-  hipLaunchKernelGGL((bgemm_kernel<TM, TN, LN>), dim3((unsigned)(8 * per_xcd)), dim3(512), C::LDS_BYTES, s, a, n_mt, n_nt,
+  hipLaunchKernelGGL((bgemm_kernel<TM, TN, LN, EXT>), dim3((unsigned)(8 * per_xcd)), dim3(512), C::LDS_BYTES, s, a, n_mt, n_nt,
                      per_xcd, total);
   return (int)hipGetLastError();
+}
+
+// does the launch need bg_epilogue_ext?
+inline bool bg_extended(const hsp_conv1d_args& a) {
+  return a.mask_mode != HSP_MASK_NONE || a.cscale || a.accumulate || a.scale != 1.0f || a.post_scale != 1.0f || a.split_row > 0;
 }
 
 template <int TM, int TN>
@@ -366,7 +442,9 @@ int bg_go(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     plan_out[0] = C::BM; plan_out[1] = C::BN; plan_out[2] = -2; plan_out[3] = C::LDS_BYTES;
     return 0;
   }
-  return a.ln_c1 ? bg_launch<TM, TN, true>(a, s, n_mt, n_nt, (int)total) : bg_launch<TM, TN, false>(a, s, n_mt, n_nt, (int)total);
+  if (bg_extended(a)) return bg_launch<TM, TN, false, true>(a, s, n_mt, n_nt, (int)total);   // never with ln_c1 (hsp_bgemm_try)
+  return a.ln_c1 ? bg_launch<TM, TN, true, false>(a, s, n_mt, n_nt, (int)total)
+                 : bg_launch<TM, TN, false, false>(a, s, n_mt, n_nt, (int)total);
 }
 
 }  // namespace
@@ -377,29 +455,37 @@ int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (BG_DBG(a, 1 << 22)) return -1;
   if (a.K != 1 || a.stride != 1 || a.pad != 0 || a.prologue != HSP_PRO_NONE || a.rows != HSP_ROWS_PLAIN) return -1;
-  if (a.x_ts != 1 || a.Lin != a.ncols || a.Lout != a.ncols || a.split_row) return -1;
+  if (a.x_ts != 1 || a.Lin != a.ncols || a.Lout != a.ncols) return -1;
   if ((a.Cin & 3) || (a.ncols & 3) || (a.x_bs & 3) || (a.x_cs & 3) || !al16(a.x) || !al16(a.w) || (a.w_ld & 3)) return -1;
   if (a.Cin < 96 || a.Cin > 8192) return -1;
   if (a.ln_c1 && !(a.ln_eps > 0.0f)) return -1;
-  // plain epilogue only (bg_epilogue); 32-bit lane offsets of four rows
-  if (a.mask_mode != HSP_MASK_NONE || a.cscale || a.accumulate || a.scale != 1.0f || a.post_scale != 1.0f) return -1;
+  if (a.mask_mode != HSP_MASK_NONE && !a.mask) return -1;
   if (a.act != HSP_ACT_NONE && a.act != HSP_ACT_RELU && a.act != HSP_ACT_GELU_TANH) return -1;
+  // the epilogues address a row as uniform base + 32-bit lane offset and test bounds per group of four rows
   if (a.y_cs >= (1 << 24) || a.res_cs >= (1 << 24) || (a.Cout & 3)) return -1;
+  const bool ext = bg_extended(a);
+  if (ext && a.ln_c1) return -1;                          // the extended epilogue is not built with the fused LayerNorm
+  if (a.split_row) {                                      // second output: whole 64-row tiles (64 x 64 shape only)
+    if (a.split_row < 0 || (a.split_row % 64) || a.split_row >= a.Cout || !a.y2 || a.y2_cs >= (1 << 24)) return -1;
+    if (a.mask_mode2 != HSP_MASK_NONE && !a.mask) return -1;
+  }
 #ifdef HSP_TUNING
-  if (a.debug & (1 << 18)) return bg_go<2, 2>(a, s, plan_out);
-  if (a.debug & (1 << 19)) return bg_go<2, 1>(a, s, plan_out);
-  if (a.debug & (1 << 21)) return bg_go<1, 2>(a, s, plan_out);
+  if (!a.split_row) {
+    if (a.debug & (1 << 18)) return bg_go<2, 2>(a, s, plan_out);
+    if (a.debug & (1 << 19)) return bg_go<2, 1>(a, s, plan_out);
+    if (a.debug & (1 << 21)) return bg_go<1, 2>(a, s, plan_out);
+  }
   if (a.debug & (1 << 23)) return bg_go<1, 1>(a, s, plan_out);
 #endif
   // Tile choice (tools/gemm_bench.py, profiles/r03_bgemm_bench.txt).  64 x 64 tiles at two workgroups per CU are the
   // default: a second resident tile covers the first one's 1.8-us start and its epilogue, which a lone 128 x 128
-  // tile per CU leaves exposed, and up to 3 200 columns that outweighs the doubled L2 traffic.  Below ~120 tiles the
+  // tile per CU leaves exposed, and up to 3 200 columns that outweighs the doubled L2 traffic.  Below ~96 tiles the
   // latency-oriented kernels win (7-11 us floors against 9.5-11.5 here); from ~850 tiles (1104 x 3 200) the
   // 128 x 128 shape is ahead (33 against 35 us).
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.ncols + bn - 1) / bn) * a.B; };
   auto waste_ok = [&](int bm) { return 4 * (int64_t)(((a.M + bm - 1) / bm) * bm - a.M) <= a.M; };
   const int64_t t64 = tiles(64, 64);
-  if (t64 < 120) return -1;
-  if (t64 >= 850 && waste_ok(128) && a.ncols >= 512) return bg_go<2, 2>(a, s, plan_out);
+  if (t64 < 96) return -1;
+  if (t64 >= 850 && waste_ok(128) && a.ncols >= 512 && !a.split_row) return bg_go<2, 2>(a, s, plan_out);
   return bg_go<1, 1>(a, s, plan_out);
 }

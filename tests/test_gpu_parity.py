@@ -829,6 +829,108 @@ def test_tts_from_prompt_with_denoiser(mel_fn, device):
         IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, denoise_ratio=0.8, dur=dur, noise=noise)
 
 
+@pytest.mark.parametrize("cin,cout,N,B,flags", [
+    (276, 1104, 3200, 1, "ln,relu"),              # 128 x 128 tiles (>= 850 64-tiles), K tail of 36 channels
+    (276, 828, 1604, 1, "ln"),                     # 64 x 64, M tail (828 = 12 x 64 + 60), N tail (1604 = 25 x 64 + 4)
+    (276, 276, 3200, 1, "res"),                    # plain epilogue with residual, M tail of 20 rows
+    (1104, 276, 1600, 1, "res"),                   # 23 stages: the ring recycles its slots
+    (192, 576, 200, 8, ""),                        # per-utterance batches (DiT qkv), column tail of 8
+    (768, 192, 200, 16, "mask,cscale,res"),        # DiT fc2 / proj form: (W y + b) * mask * gate + x
+    (192, 96, 200, 32, "maskboth,neg,res"),        # coupling `post` form: (x1 - post(h) * mask) * mask
+    (192, 192, 200, 24, "gelu,acc"),               # activation, running sum + post_scale
+    (100, 132, 1280, 2, "ln,relu"),                # odd sizes: K = 2 stages + 4 channels, M = 2 x 64 + 4
+])
+def test_block_token_gemm_vs_torch(cin, cout, N, B, flags, device):
+    """hsp_bgemm.hip (the throughput-oriented token GEMM behind hsp_conv1d_mfma_f32, round 3) against torch fp32 on the
+    CPU, every epilogue form the host layers use; the plan entry point confirms that the launch really took it."""
+    import ctypes as C
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import hip_layers
+    from megatts2_hierspeechpp_amd.ttv_v1.transformer_mega import LayerNorm
+    fl = set(flags.split(",")) - {""}
+    g = torch.Generator().manual_seed(cin * 7 + N)
+    lin, norm = hip_layers.LinearCT(cin, cout), LayerNorm(cin)
+    w, bias = torch.randn(cout, cin, generator=g) / cin ** 0.5, 0.1 * torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+    lin.weight.data, lin.bias.data, norm.weight.data, norm.bias.data = w.clone(), bias.clone(), gamma.clone(), beta.clone()
+    if "ln" in fl:
+        lin.fuse_input_layernorm(norm)
+    hip_layers.finalize(torch.nn.ModuleList([norm, lin]), device)
+    x = 2.0 * torch.randn(B, cin, N, generator=g) + 1.0
+    xin = torch.nn.functional.layer_norm(x.transpose(1, 2), (cin,), gamma, beta, 1e-5).transpose(1, 2) if "ln" in fl else x
+    ref = torch.nn.functional.conv1d(xin, w[:, :, None], bias)
+    kw = {}
+    if "relu" in fl:
+        ref, kw["act"] = torch.relu(ref), L.ACT_RELU
+    if "gelu" in fl:
+        ref, kw["act"] = torch.nn.functional.gelu(ref, approximate="tanh"), L.ACT_GELU_TANH
+    mask = (torch.rand(B, 1, N, generator=g) > 0.3).float()
+    if "mask" in fl or "maskboth" in fl:
+        ref = ref * mask
+        kw.update(mask=mask.to(device), mask_mode=L.MASK_BOTH if "maskboth" in fl else L.MASK_PRE)
+    if "cscale" in fl:
+        cs = torch.randn(B, cout, generator=g)
+        ref = ref * cs[:, :, None]
+        kw["cscale"] = cs.to(device)
+    if "neg" in fl:
+        ref = -ref
+        kw["scale"] = -1.0
+    if "res" in fl:
+        res = torch.randn(B, cout, N, generator=g)
+        ref = ref + res
+        kw["res"] = res.to(device)
+    if "maskboth" in fl:
+        ref = ref * mask
+    if "acc" in fl:
+        y0 = torch.randn(B, cout, N, generator=g)
+        ref = (ref + y0) * 0.5
+        kw.update(out=y0.clone().to(device), accumulate=True, post_scale=0.5)
+    plans = []
+
+    def hook(kind, flops, nbytes, e0, e1, la):
+        plan = (C.c_int32 * 4)()
+        L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
+        plans.append(tuple(plan))
+
+    hip_layers.LAUNCH_HOOK = hook
+    try:
+        got = lin(x.to(device), **kw).cpu().numpy()
+    finally:
+        hip_layers.LAUNCH_HOOK = None
+    assert len(plans) == 1 and plans[0][2] == -2, f"not the block token GEMM: plan {plans}"
+    assert (plans[0][0], plans[0][1]) == ((128, 128) if cout == 1104 else (64, 64)), plans
+    _close(got, ref.numpy(), f"bgemm {cin}->{cout} N={N} B={B} {flags}")
+
+
+def test_block_token_gemm_second_output(device):
+    """hsp_conv1d_args.split_row on the block token GEMM (WN res_skip layer of a whole front group: rows [0, H) ->
+    x + res_skip * mask, rows [H, 2H) -> running skip sum) against the two single-output launches."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    g = torch.Generator().manual_seed(5)
+    H_, B, T = 192, 8, 200                        # 6 x 4 x 8 = 192 tiles of 64 x 64
+    lay = Conv1d(H_, 2 * H_, 1, weight_norm=True)
+    with torch.no_grad():
+        for p_ in lay.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        lay.weight_g.fill_(0.5)
+    finalize(lay, device)
+    acts, x = torch.randn(B, H_, T, generator=g).to(device), torch.randn(B, H_, T, generator=g).to(device)
+    mask = (torch.rand(B, 1, T, generator=g) > 0.2).float().to(device)
+    prev = torch.randn(B, H_, T, generator=g).to(device)
+    x_ref = lay(acts, row_range=(0, H_), res=x, mask=mask, mask_mode=L.MASK_POST)
+    out_ref = lay(acts, row_range=(H_, 2 * H_), out=prev.clone(), accumulate=True)
+    both = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, prev.clone(), True))
+    assert both is not None
+    _close(both[0].cpu().numpy(), x_ref.cpu().numpy(), "bgemm split: first output")
+    _close(both[1].cpu().numpy(), out_ref.cpu().numpy(), "bgemm split: accumulated second output")
+    w = lay._folded()[:, :, 0].cpu() if hasattr(lay, "_folded") else None
+    if w is not None:                              # and against torch, so that the comparison is not kernel against kernel
+        full = torch.nn.functional.conv1d(acts.cpu(), w[:, :, None], lay.bias.data.cpu())
+        _close(both[0].cpu().numpy(), ((x.cpu() + full[:, :H_]) * mask.cpu()).numpy(), "bgemm split: first output vs torch")
+        _close(both[1].cpu().numpy(), (prev.cpu() + full[:, H_:]).numpy(), "bgemm split: second output vs torch")
+
+
 def test_second_output_gemm_matches_two_launches(device):
     """hsp_conv1d_args.split_row: one token-GEMM launch for the two row halves of a WN res_skip layer
     (modules.py:166-174) == the two separate launches, bit for bit; shapes without a fused kernel are refused
