@@ -165,6 +165,11 @@ typedef struct hsp_conv1d_args {
   int32_t mask_mode2;
   float* y2;
   int64_t y2_bs, y2_cs;
+  /* Column stride of `res` in elements (0 or 1: unit).  Only the register-path token GEMM reads a residual at another
+   * stride -- the last layer of the PLM loop adds the last position of every utterance, columns T-1, 2T-1, ... of the
+   * layer input, to a [D, B] output without a gather launch in between (ttv_v1/transformer_mega.py:118-131 on the
+   * last position only); any other kernel / shape refuses res_ts > 1 with HSP_EINVAL. */
+  int64_t res_ts;
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Two kernels sit
@@ -175,7 +180,8 @@ int hsp_conv1d_mfma_f32(const hsp_conv1d_args* a, void* stream);
  * rows must be PLAIN; prologue NONE/LRELU/SILU. */
 int hsp_conv1d_direct_f32(const hsp_conv1d_args* a, void* stream);
 /* which kernel / tile configuration hsp_conv1d_mfma_f32 would pick: writes BM, BN, KC, LDS bytes
- * (KC > 0: the conv kernel's chunk depth; KC = 0: the LDS-DMA token GEMM; KC = -1: the register-path token GEMM) */
+ * (KC > 0: the conv kernel's chunk depth; KC = 0: the LDS-DMA token GEMM; KC = -1: the register-path token GEMM;
+ * KC = -2: the block token GEMM of hsp_bgemm.hip, 64 x 64 or 128 x 128 tiles) */
 int hsp_conv1d_mfma_plan(const hsp_conv1d_args* a, int32_t out4[4]);
 
 /* --------------------------------------- feature producer of inference_vc.py */
@@ -313,6 +319,14 @@ int hsp_plm_embed_f32(const float* tc, int64_t tc_bs, int64_t tc_cs, int32_t Dtc
                       int64_t codes_bs, const float* emb, int32_t Demb, int32_t n_emb, const float* pe_t,
                       int32_t P, const float* alpha, float* x, int64_t x_bs, int64_t x_cs, int32_t B, int32_t n,
                       void* stream);
+/* The same for step n >= 2 of the greedy loop with the choice of the PREVIOUS step folded in (one launch per step less):
+ * first codes[b, n - 1] = argmax_c logits[b * l_bs + c * l_cs] (first maximal index on ties, as hsp_argmax_f32; the
+ * value is also stored to `codes`), then x as above.  `logits` = the n_logits scores of step n - 1
+ * (ttv_v1/t2w2v_transformer.py:716-717 followed by :710-713 of the next iteration). */
+int hsp_plm_embed_step_f32(const float* tc, int64_t tc_bs, int64_t tc_cs, int32_t Dtc, int64_t* codes,
+                           int64_t codes_bs, const float* emb, int32_t Demb, int32_t n_emb, const float* pe_t,
+                           int32_t P, const float* alpha, float* x, int64_t x_bs, int64_t x_cs, int32_t B, int32_t n,
+                           const float* logits, int64_t l_bs, int64_t l_cs, int32_t n_logits, void* stream);
 /* out[b * out_bs] = argmax_c logits[b * l_bs + c * l_cs], first maximal index on ties :
  * logits.argmax(dim=-1) of the greedy loop (ttv_v1/t2w2v_transformer.py:716-717) */
 int hsp_argmax_f32(const float* logits, int64_t l_bs, int64_t l_cs, int32_t B, int32_t N, int64_t* out,

@@ -44,7 +44,7 @@ class Conv1dArgs(C.Structure):
         ("accumulate", C.c_int32), ("post_scale", C.c_float), ("debug", C.c_int32),
         ("ln_c1", _fp), ("ln_eps", C.c_float),
         ("split_row", C.c_int32), ("accumulate2", C.c_int32), ("mask_mode2", C.c_int32), ("y2", _fp),
-        ("y2_bs", C.c_int64), ("y2_cs", C.c_int64),
+        ("y2_bs", C.c_int64), ("y2_cs", C.c_int64), ("res_ts", C.c_int64),
     ]
 
 
@@ -84,6 +84,9 @@ SIGNATURES = {
     "hsp_axpby_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_int64, _fp]),
     "hsp_plm_embed_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int32, C.c_int32,
                                     _fp, C.c_int32, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp]),
+    "hsp_plm_embed_step_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int32, C.c_int32,
+                                         _fp, C.c_int32, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
+                                         C.c_int64, C.c_int32, _fp]),
     "hsp_argmax_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64, _fp]),
     "hsp_embedding_sum_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp,
                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp]),

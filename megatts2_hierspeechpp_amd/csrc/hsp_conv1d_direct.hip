@@ -169,6 +169,7 @@ extern "C" int hsp_conv1d_direct_f32(const hsp_conv1d_args* ap, void* stream) {
   if (a.stride < 1 || a.dil < 1 || a.rows != HSP_ROWS_PLAIN || a.Cout > a.M || a.w_ld < a.M) return HSP_EINVAL;
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_SILU) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
+  if (a.res && a.res_ts > 1) return HSP_EINVAL;   // strided residual: register-path token GEMM only
   if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused LayerNorm / second output: token-GEMM path only
   if (cout1_fast(a)) {
     const int n_tiles = (a.Lout + 1023) / 1024;

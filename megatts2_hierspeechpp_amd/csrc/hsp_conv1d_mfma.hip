@@ -26,6 +26,7 @@ int validate(const hsp_conv1d_args& a) {
   if ((int64_t)a.Cin * a.x_cs + (int64_t)a.Lin * a.x_ts >= (1ll << 31) || a.x_cs < 0 || a.x_ts < 0) return HSP_EINVAL;
   if (a.y_cs < 0 || (int64_t)a.Cout * a.y_cs + a.Lout >= (1ll << 31)) return HSP_EINVAL;
   if (a.res && (a.res_cs < 0 || (int64_t)a.Cout * a.res_cs + a.Lout >= (1ll << 31))) return HSP_EINVAL;
+  if (a.res_ts < 0 || (a.res && a.res_ts > 1 && (int64_t)a.Cout * a.res_cs + (int64_t)a.Lout * a.res_ts >= (1ll << 31))) return HSP_EINVAL;
   if (a.prologue == HSP_PRO_ACT1D && (!a.alpha_exp || !a.beta_inv || !a.filt || a.x_ts != 1)) return HSP_EINVAL;
   if (!a.zeros || (reinterpret_cast<uintptr_t>(a.zeros) & 15) != 0) return HSP_EINVAL;
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_ACT1D) return HSP_EINVAL;
@@ -49,6 +50,11 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // 36 us against 67 us at C = 128, k = 7) for a quarter of the work, so the small shape wins up to 64 big tiles,
   // ties up to 128 and loses 2x beyond (tools/conv_sweep.py, profiles/r02_tile_threshold.txt).
   const bool short_seq = (int64_t)((a.M + 127) / 128) * ((a.ncols + 127) / 128) * a.B <= 128;
+  // a residual read at a column stride: the register-path token GEMM or nothing
+  if (a.res && a.res_ts > 1) {
+    const int e = hsp_rgemm_try(a, s, plan_out);
+    return e >= 0 ? e : HSP_EINVAL;
+  }
   // 1x1 GEMMs with enough outputs for about one 128 x 128 / 128 x 64 tile per CU (the PLM loop beyond ~60 prefix
   // positions): the throughput-oriented token GEMM (hsp_bgemm.hip)
   if (a.K == 1 && !HSP_DBG(a, 128)) {

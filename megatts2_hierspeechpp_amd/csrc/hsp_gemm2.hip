@@ -572,7 +572,7 @@ bool g2_consumes(const hsp_conv1d_args& in, const hsp_conv1d_args& o, int acts_c
          o.x == in.y && o.x_bs == in.y_bs && o.x_cs == in.y_cs && o.x_ts == 1 && o.B == in.B && o.Cin == acts_channels &&
          o.Lin == in.Lout && o.Lout == in.Lout && o.ncols == in.Lout && !o.ln_c1 && !o.split_row && o.M == o.Cout &&
          (o.Cout & 31) == 0 && (o.w_ld & 3) == 0 && g2_al16(o.w) && o.y && o.y != in.x &&
-         (o.mask_mode == HSP_MASK_NONE || o.mask) && !(o.res && o.accumulate);
+         (o.mask_mode == HSP_MASK_NONE || o.mask) && !(o.res && o.accumulate) && !(o.res && o.res_ts > 1);
 }
 
 template <int NB2PW, bool GATE, bool MULTI>

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
   const int ncol = nb + l32;
   const int nc = min(ncol, a.ncols - 1);
   const float mk = a.mask_mode != HSP_MASK_NONE ? a.mask[(int64_t)b * a.mask_bs + nc] : 1.0f;
-  const float* resb = a.res ? a.res + (int64_t)b * a.res_bs + nc : nullptr;
+  const float* resb = a.res ? a.res + (int64_t)b * a.res_bs + (int64_t)nc * (a.res_ts > 1 ? a.res_ts : 1) : nullptr;
   float* yb = a.y + (int64_t)b * a.y_bs + nc;
   float bv[4], rv[4], yv[4], cs[4], c1[4];
 #pragma unroll
@@ -198,7 +198,7 @@ int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // prologue), 14 against 29 us at K = 1104 -- and a tie around 1 600 x 828; beyond that the LDS kernel's operand
   // reuse wins (3 200 columns: 34-49 us against 43-52), so larger launches stay there.
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.ncols + bn - 1) / bn) * a.B; };
-  const bool forced = RG_DBG(a, 8 | 16);
+  const bool forced = RG_DBG(a, 8 | 16) || (a.res && a.res_ts > 1);   // a strided residual has no other kernel
   const int64_t outs = (int64_t)a.M * a.ncols * a.B;
   if (!forced && a.x_ts == 1 && (outs > 1400000 || outs * a.Cin > 500000000)) return -1;
   // tile: 64 x 32 where that still fills the chip, else 32 x 32 (a 64 x 64 / K-split-2 form was measured and lost)

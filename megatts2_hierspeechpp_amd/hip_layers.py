@@ -669,8 +669,10 @@ def _set_epilogue(a, act, cbias, mask, mask_mode, cscale, scale, res, accumulate
         a.cscale, a.cscale_bs = L.fptr(cscale), cscale.stride(0)
     a.scale = float(scale)
     if res is not None:
-        assert res.shape == out.shape and (res.stride(2) == 1 or res.shape[2] == 1)
+        assert res.shape == out.shape
         a.res, a.res_bs, a.res_cs = L.fptr(res), res.stride(0), res.stride(1)
+        if res.stride(2) != 1 and res.shape[2] != 1:
+            a.res_ts = res.stride(2)      # hsp_conv1d_args.res_ts: the register-path token GEMM only (else HSP_EINVAL)
     a.accumulate = 1 if accumulate else 0
     a.post_scale = float(post_scale)
 

@@ -101,27 +101,35 @@ class Megatts2PLM1(nn.Module):
         self.arena = _finalize(self, device, materialize)
         return self
 
-    def _embed(self, tc, codes, n):
+    def _embed(self, tc, codes, n, prev_logits=None):
         """[1, d_model, Np]: utterance b occupies columns b*n .. b*n+n-1; Np = B*n rounded up to a multiple
-        of 4 (16-B rows for the token GEMM's DMA), padding columns are zero."""
+        of 4 (16-B rows for the token GEMM's DMA), padding columns are zero.  ``prev_logits`` [1, vq_bins, B]: the
+        scores of step n-1, whose argmax this launch takes (and stores to ``codes[:, n-1]``) before it embeds."""
         B = tc.shape[0]
         x = torch.empty(1, self.d_model, (B * n + 3) & ~3, dtype=torch.float32, device=tc.device)
-        L.check(L.lib().hsp_plm_embed_f32(L.fptr(tc), tc.stride(0), tc.stride(1), self.tc_latent_dim, L.ptr(codes),
-                                          codes.stride(0), L.fptr(self.pc_embedding._w), self.vq_dim,
-                                          self.pc_embedding.num_embeddings, L.fptr(self.pos_emb._pe_t),
-                                          self.pos_emb.N_POS, L.fptr(self.pos_emb._alpha), L.fptr(x), n, x.shape[2], B, n,
-                                          L.stream_ptr()), "hsp_plm_embed_f32")
+        head = (L.fptr(tc), tc.stride(0), tc.stride(1), self.tc_latent_dim, L.ptr(codes), codes.stride(0),
+                L.fptr(self.pc_embedding._w), self.vq_dim, self.pc_embedding.num_embeddings, L.fptr(self.pos_emb._pe_t),
+                self.pos_emb.N_POS, L.fptr(self.pos_emb._alpha), L.fptr(x), n, x.shape[2], B, n)
+        if prev_logits is None:
+            L.check(L.lib().hsp_plm_embed_f32(*head, L.stream_ptr()), "hsp_plm_embed_f32")
+        else:
+            lg = prev_logits
+            assert lg.shape == (1, self.vq_bins, B) and lg.stride(2) == 1
+            L.check(L.lib().hsp_plm_embed_step_f32(*head, L.fptr(lg), 1, lg.stride(1), self.vq_bins, L.stream_ptr()),
+                    "hsp_plm_embed_step_f32")
         return x
 
     @_entry
-    def step_logits(self, tc_latent, codes, n, out=None):
+    def step_logits(self, tc_latent, codes, n, out=None, prev_logits=None):
         """Logits of position n-1 given the first n columns of ``tc_latent`` [B, 256, T] and of
-        ``codes`` [B, >= n] (go token first): one pass of the loop body (:710-716) -> [1, vq_bins, B]."""
+        ``codes`` [B, >= n] (go token first): one pass of the loop body (:710-716) -> [1, vq_bins, B].
+        With ``prev_logits`` (the result of the call for n-1) ``codes[:, n-1]`` is not read but first set to their
+        argmax, inside the embedding launch."""
         B = tc_latent.shape[0]
         # the last layer only produces the last position of every utterance when those B columns form a
         # 16-B addressable matrix for the fused-LayerNorm GEMM; otherwise it runs in full
         last_only = B % 4 == 0
-        x = self.plm(self._embed(tc_latent, codes, n), batch=(B, n), last_only=last_only)
+        x = self.plm(self._embed(tc_latent, codes, n, prev_logits), batch=(B, n), last_only=last_only)
         if not last_only:
             x = Fh.copy_strided(x[0][:, :B * n].reshape(self.d_model, B, n)[:, :, n - 1].unsqueeze(0))
         return self.predict_layer(x, out=out)
@@ -138,10 +146,13 @@ class Megatts2PLM1(nn.Module):
         codes[:, 0] = self.GO_ID
         all_logits = torch.empty(T, self.vq_bins, B, dtype=torch.float32, device=tc_latent.device) if return_logits \
             else None
+        lg = None
         for t in range(T):
-            lg = self.step_logits(tc_latent, codes, t + 1, out=all_logits[t:t + 1] if return_logits else None)
-            L.check(L.lib().hsp_argmax_f32(L.fptr(lg), 1, B, B, self.vq_bins, L.ptr(codes[:, t + 1:]),
-                                           codes.stride(0), L.stream_ptr()), "hsp_argmax_f32")
+            # the greedy choice of step t-1 is taken inside step t's embedding launch; only the last step's needs its own
+            lg = self.step_logits(tc_latent, codes, t + 1, out=all_logits[t:t + 1] if return_logits else None,
+                                  prev_logits=lg)
+        L.check(L.lib().hsp_argmax_f32(L.fptr(lg), 1, B, B, self.vq_bins, L.ptr(codes[:, T:]), codes.stride(0),
+                                       L.stream_ptr()), "hsp_argmax_f32")
         return (codes[:, 1:], all_logits.permute(2, 0, 1)) if return_logits else codes[:, 1:]
 
 

@@ -103,7 +103,8 @@ class TransformerEncoderLayer(nn.Module):
         res = x
         if last_only:
             B, T = batch
-            res = Fh.copy_strided(x[0][:, :B * T].reshape(-1, B, T)[:, :, T - 1].unsqueeze(0))
+            # the last position of every utterance, read in place at column stride T (hsp_conv1d_args.res_ts)
+            res = x[0][:, :B * T].reshape(-1, B, T)[:, :, T - 1].unsqueeze(0)
         x = self.attn(x, mask=mask, res=res, batch=batch, last_only=last_only)   # norm1 fused into q/k/v
         h = self.ff["0"](x, act=L.ACT_RELU)                                       # norm2 fused into ff.0
         return self.ff["3"](h, res=x)

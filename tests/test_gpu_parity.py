@@ -931,6 +931,30 @@ def test_block_token_gemm_second_output(device):
         _close(both[1].cpu().numpy(), (prev.cpu() + full[:, H_:]).numpy(), "bgemm split: second output vs torch")
 
 
+def test_token_gemm_reads_a_strided_residual_in_place(device):
+    """hsp_conv1d_args.res_ts: the last layer of the PLM loop adds the LAST position of every utterance (columns T-1,
+    2T-1, ... of the layer input) to a [D, B] product without a gather launch; other kernels refuse such a residual."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, LinearCT, finalize
+    g = torch.Generator().manual_seed(11)
+    D, B, T = 276, 16, 37
+    lin = LinearCT(D, D)
+    w, bias = torch.randn(D, D, generator=g) / D ** 0.5, 0.1 * torch.randn(D, generator=g)
+    lin.weight.data, lin.bias.data = w.clone(), bias.clone()
+    finalize(lin, device)
+    x = torch.randn(1, D, B * T, generator=g)
+    o = torch.randn(1, D, B * T, generator=g)
+    last = lambda m: m[0].reshape(D, B, T)[:, :, T - 1].unsqueeze(0)       # [1, D, B] view, column stride T
+    ref = torch.nn.functional.conv1d(last(o).contiguous(), w[:, :, None], bias) + last(x)
+    xd, od = x.to(device), o.to(device)
+    got = lin(last(od), res=last(xd))
+    _close(got.cpu().numpy(), ref.numpy(), "strided residual")
+    conv = Conv1d(D, D, 3, padding=1)
+    finalize(conv, device)
+    with pytest.raises(L.HspError):                                         # a k = 3 conv has no such path
+        conv(torch.randn(1, D, B, generator=g).to(device), res=last(xd))
+
+
 def test_second_output_gemm_matches_two_launches(device):
     """hsp_conv1d_args.split_row: one token-GEMM launch for the two row halves of a WN res_skip layer
     (modules.py:166-174) == the two separate launches, bit for bit; shapes without a fused kernel are refused

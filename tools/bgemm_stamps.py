@@ -20,10 +20,10 @@ def launch(kind, fn, a, flops, nbytes, soft=False, keep=()):
 
 
 hip_layers._launch = launch
-for tile, bit in (("128x128", 1 << 18), ("128x64", 1 << 19)):
+for tile, bit in (("128x128", 1 << 18), ("128x64", 1 << 19), ("64x64", 1 << 23)):
     for extra in (0, 1, 2):
         hip_layers.DEBUG_FLAGS = (1 << 20) | bit | extra
-        for K, N, M in ((276, 128, 128), (276, 3200, 1104), (1104, 3200, 1104)):
+        for K, N, M in ((276, 128, 128), (276, 3200, 1104), (1104, 3200, 276)):
             lin = hip_layers.LinearCT(K, M)
             lin.weight.data.normal_(0, 0.05)
             hip_layers.finalize(lin, dev)

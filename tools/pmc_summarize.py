@@ -17,7 +17,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = ["conv1d_mfma_kernel", "gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "act1d_seg_kernel", "act1d_kernel",
+CLASSES = ["conv1d_mfma_kernel", "gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "bgemm_kernel", "act1d_seg_kernel", "act1d_kernel",
            "mha_mfma_kernel", "mha_tok_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel"]
 B, T = 32, 200
 STEPS = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
@@ -74,7 +74,7 @@ res = {
     "conv1d_mfma_bytes_per_step": three(conv),
     "act1d_seg_bytes_per_step": three(act),
 }
-for name in ("gemm2_kernel", "tokgemm_kernel", "rgemm_kernel"):
+for name in ("gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "bgemm_kernel"):
     if name in out:
         res[name + "_bytes_per_step"] = three(out[name])
 json.dump(res, open(dst, "w"), indent=1)

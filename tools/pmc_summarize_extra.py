@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from megatts2_hierspeechpp_amd.build import source_id  # noqa: E402
 
-CLASSES = ["conv1d_mfma_kernel", "gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "act1d_seg_kernel", "act1d_kernel",
+CLASSES = ["conv1d_mfma_kernel", "gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "bgemm_kernel", "act1d_seg_kernel", "act1d_kernel",
            "mha_tok_kernel", "mha_mfma_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel",
            "linear_interp", "plm_embed", "argmax"]
 PASSES = 2
