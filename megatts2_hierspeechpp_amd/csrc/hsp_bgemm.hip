@@ -277,23 +277,54 @@ __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, 
     const bool mok = m0 + cw < a.M, nok = n0 + cx < a.ncols;
     const float* wsrc = a.w + m0 + cw;
     const float* xsrc = a.x + (int64_t)b * a.x_bs + n0 + cx;
+    // Fast staging (the conv kernel's dma_w_fast idea): the fp32 MFMAs of the consumer wave on this SIMD run on the
+    // VALU's own lanes, so every vector instruction of the address arithmetic (a 64-bit multiply-add, compares,
+    // selects: ~45 cycles per DMA instruction in the general form below, a fifth of a stage's matrix time) is paid in
+    // matrix time.  For a tile that lies inside the matrix and a stage that lies inside K -- all but the edge tiles
+    // and the last stage -- a lane's byte offset is computed ONCE and each instruction adds it to a wave-uniform
+    // base that the scalar unit walks: one vector instruction per DMA.
+    const bool wfast = m0 + C::BM <= a.M, xfast = n0 + C::BN <= a.ncols && a.x_cs < (1 << 26);
+    // this lane's source inside the tile's first staged rows; hsp_conv1d_mfma_f32's validation bounds the element
+    // offsets of the weight matrix and of one utterance to 31 bits
+    const float* wlane = a.w + m0 + rw * a.w_ld + cw;
+    const float* xlane = a.x + (int64_t)b * a.x_bs + n0 + (xfast ? rx * (int)a.x_cs : 0) + cx;
+    const int wld = a.w_ld, xcs = (int)a.x_cs;
     auto issue = [&](int s) __attribute__((always_inline)) {
       float* Ws = lds + (s % C::NST) * C::STAGE;
       float* Xs = Ws + BG_KS * C::BM;
       const int k0 = s * BG_KS;
+      const bool kfull = k0 + BG_KS <= K;
+      if (wfast && kfull) {
 #pragma unroll
-      for (int q = 0; q < C::NIW / 4; ++q) {
-        const int r0 = (pw + 4 * q) * RPIW;
-        const int k = k0 + r0 + rw;
-        const float* src = (mok && k < K) ? wsrc + (int64_t)k * a.w_ld : a.zeros;
-        __builtin_amdgcn_global_load_lds(BG_GPTR(src), BG_LPTR(Ws + r0 * C::BM), 16, 0, 0);
+        for (int q = 0; q < C::NIW / 4; ++q) {
+          const int r0 = (pw + 4 * q) * RPIW;
+          const int eo = __builtin_amdgcn_readfirstlane((k0 + r0) * wld);     // scalar unit
+          __builtin_amdgcn_global_load_lds(BG_GPTR(wlane + eo), BG_LPTR(Ws + r0 * C::BM), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < C::NIW / 4; ++q) {
+          const int r0 = (pw + 4 * q) * RPIW;
+          const int k = k0 + r0 + rw;
+          const float* src = (mok && k < K) ? wsrc + (int64_t)k * a.w_ld : a.zeros;
+          __builtin_amdgcn_global_load_lds(BG_GPTR(src), BG_LPTR(Ws + r0 * C::BM), 16, 0, 0);
+        }
       }
+      if (xfast && kfull) {
 #pragma unroll
-      for (int q = 0; q < C::NIX / 4; ++q) {
-        const int r0 = (pw + 4 * q) * RPIX;
-        const int k = k0 + r0 + rx;
-        const float* src = (nok && k < K) ? xsrc + (int64_t)k * a.x_cs : a.zeros;
-        __builtin_amdgcn_global_load_lds(BG_GPTR(src), BG_LPTR(Xs + r0 * C::BN), 16, 0, 0);
+        for (int q = 0; q < C::NIX / 4; ++q) {
+          const int r0 = (pw + 4 * q) * RPIX;
+          const int eo = __builtin_amdgcn_readfirstlane((k0 + r0) * xcs);
+          __builtin_amdgcn_global_load_lds(BG_GPTR(xlane + eo), BG_LPTR(Xs + r0 * C::BN), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < C::NIX / 4; ++q) {
+          const int r0 = (pw + 4 * q) * RPIX;
+          const int k = k0 + r0 + rx;
+          const float* src = (nok && k < K) ? xsrc + (int64_t)k * a.x_cs : a.zeros;
+          __builtin_amdgcn_global_load_lds(BG_GPTR(src), BG_LPTR(Xs + r0 * C::BN), 16, 0, 0);
+        }
       }
     };
     const int npre = nstage < C::NST ? nstage : C::NST;
