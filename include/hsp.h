@@ -172,9 +172,11 @@ typedef struct hsp_conv1d_args {
   int64_t res_ts;
 } hsp_conv1d_args;
 
-/* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Two kernels sit
- * behind this entry point: the implicit-GEMM conv kernel (any K / dilation / prologue / row mode) and,
- * for 1x1 convs over a short column axis (or with ln_c1), the latency-oriented token GEMM. */
+/* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Behind this entry point: the
+ * implicit-GEMM conv kernel (any K / dilation / prologue / row mode) and, for 1x1 convs over token columns (or with
+ * ln_c1 / split_row), three token GEMMs -- the register-path and the LDS-DMA kernel (latency-oriented, up to a few
+ * hundred thousand outputs) and the block token GEMM (64 x 64 / 128 x 128 tiles, from ~96 tiles of 64 x 64 upward);
+ * hsp_conv1d_mfma_plan tells which one a launch takes. */
 int hsp_conv1d_mfma_f32(const hsp_conv1d_args* a, void* stream);
 /* VALU path: any shape (Cin = 1, Cout = 1, stride > 1, L = 1 "Linear" cases);
  * rows must be PLAIN; prologue NONE/LRELU/SILU. */
