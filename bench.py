@@ -376,7 +376,8 @@ def vocoder_roofline(args, wl, result):
         "launches_per_step": len(rec2), "kernel_ms_per_step": ms2, "achieved": fl2 / (ms2 * 1e-3) / 1e12,
         "frac": fl2 / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         "note": "HSP_FRONT_SPLITS=1 pass (one front group: WN / FFN layers in gemm2_kernel), the population BENCH_r02's "
-                "roofline.frac was computed over; the timed step does not run this mix"}
+                "roofline.frac was computed over (167 launches then; the 1x1 convs among them now run in bgemm_kernel); the "
+                "timed step does not run this mix"}
     if act_rec:
         # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
         a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)
