@@ -301,8 +301,6 @@ class SynthesizerTrn(nn.Module):
                  upsample_rates, upsample_initial_channel, upsample_kernel_sizes, gin_channels=256, prosody_size=20,
                  uncond_ratio=0., cfg=False, **kwargs):
         super().__init__()
-        if cfg:
-            raise NotImplementedError("cfg=True (classifier-free null embedding) is not on the reproduced path")
         self.spec_channels, self.segment_size = spec_channels, segment_size
         self.inter_channels, self.hidden_channels = inter_channels, hidden_channels
         self.upsample_rates = upsample_rates
@@ -313,6 +311,11 @@ class SynthesizerTrn(nn.Module):
                              upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
         self.sn = SourceNetwork(upsample_initial_channel // 2)
         self.emb_g = StyleEncoder(in_dim=80, hidden_dim=256, out_dim=gin_channels)
+        if cfg:
+            # classifier-free null speaker embedding (:628-633): torch.nn.Embedding(1, 256), key "emb.weight"
+            from .ttv_v1.t2w2v_transformer import Embedding
+            self.emb = Embedding(1, 256)
+            self.uncond_ratio = uncond_ratio
         self.cfg = cfg
 
     # ------------------------------------------------------------------ weights
@@ -321,7 +324,8 @@ class SynthesizerTrn(nn.Module):
         {'model': ...} (utils.py:19-44); keys of training-only sub-modules are skipped."""
         if "model" in state_dict and not any(k.startswith("dec.") for k in state_dict):
             state_dict = state_dict["model"]
-        sd = {k: v for k, v in state_dict.items() if not k.startswith(UNUSED_PREFIXES)}
+        skip = tuple(p for p in UNUSED_PREFIXES if not (self.cfg and p == "emb."))
+        sd = {k: v for k, v in state_dict.items() if not k.startswith(skip)}
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def finalize(self, device, materialize: bool = True):
@@ -389,14 +393,23 @@ class SynthesizerTrn(nn.Module):
     @torch.no_grad()
     def voice_conversion(self, src, src_length, trg_mel, trg_length, f0, noise_scale=0.333, uncond=False,
                          noise: Optional[torch.Tensor] = None):
-        """:652-673."""
-        if uncond:
-            raise NotImplementedError("uncond needs cfg=True")
+        """:652-673.  ``uncond`` (a model built with cfg=True): the source network and the generator are conditioned
+        on the null embedding ``emb(0) * sqrt(256)`` instead of the prompt's style vector (:669-671); the prior encoder
+        and the flows still see the prompt."""
         trg_mask = commons.sequence_mask(trg_length, trg_mel.size(2))
         g = self.emb_g(trg_mel, trg_mask).unsqueeze(-1)
         y_mask = commons.sequence_mask(src_length, src.size(2))
         z = self._latent(src, _f0_3d(f0), y_mask, g, noise, noise_scale)
+        if uncond:
+            g = self._null_g(src.shape[0])
         return self._decode(z, g)[0]
+
+    def _null_g(self, B):
+        """[B, 256, 1] = emb(0) * sqrt(256), one copy per utterance (the reference broadcasts a [1, 256, 1] tensor)."""
+        if not self.cfg:
+            raise AttributeError("'SynthesizerTrn' object has no attribute 'emb' (uncond needs a model built with cfg=True)")
+        w = self.emb._w.view(1, -1, 1).expand(B, -1, 1).contiguous()
+        return Fh.axpby(w, w, math.sqrt(256.0), 0.0)
 
     @_entry
     @torch.no_grad()
@@ -406,8 +419,8 @@ class SynthesizerTrn(nn.Module):
         are interpolated with ``denoise_ratio`` (B = 1 by construction in the reference, SURVEY.md
         App. B1).  With B source utterances trg_mel is [2B, 80, T]: the B prompts, then the B denoised
         prompts, and f0 is [B, 1, 4T]."""
-        if uncond:
-            raise NotImplementedError("uncond needs cfg=True")
+        if uncond and not self.cfg:   # the reference evaluates self.emb here (:693-695) and then does not use the result
+            raise AttributeError("'SynthesizerTrn' object has no attribute 'emb' (uncond needs a model built with cfg=True)")
         B = src.shape[0]
         assert trg_mel.shape[0] == 2 * B
         trg_mask = commons.sequence_mask(trg_length, trg_mel.size(2))

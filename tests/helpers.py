@@ -150,7 +150,7 @@ def run_oracle(meta, arrays):
         return [O.speechsr(real, t("x"), meta["factor"], "dec")]
     if kind == "vc_plain":
         return [O.synth_voice_conversion(sd, cfg, t("w2v"), t("src_length"), t("mel"), t("trg_length"), t("f0"),
-                                         meta["noise_scale"], t("noise"))]
+                                         meta["noise_scale"], t("noise"), uncond=bool(meta.get("uncond", False)))]
     if kind == "w2v":
         # synth_sd holds the renamed (weight_g / weight_v) keys the product module uses; the oracle accepts both spellings
         return [O.wav2vec2_hidden(sd, t("x"), meta["layer"])]
@@ -206,7 +206,7 @@ def build_module(meta):
         return H.Generator(192, cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"], cfg["upsample_rates"],
                            cfg["upsample_initial_channel"], cfg["upsample_kernel_sizes"], gin_channels=256)
     if kind in ("infer", "vc", "vc_plain"):
-        return H.SynthesizerTrn(641, 61440 // 320, **cfg)
+        return H.SynthesizerTrn(641, 61440 // 320, cfg=bool(meta.get("cfg", False)), **cfg)
     if kind == "rel_mha":
         from megatts2_hierspeechpp_amd import attentions
         return attentions.MultiHeadAttention(256, 256, meta["heads"], window_size=meta["window"])
@@ -324,7 +324,8 @@ def run_hip(meta, arrays, device, drop_in=False):
                                  dur=d("dur")))
         elif kind == "vc_plain":
             out = [mod.voice_conversion(d("w2v"), d("src_length"), d("mel"), d("trg_length"), d("f0"),
-                                        noise_scale=meta["noise_scale"], noise=d("noise"))]
+                                        noise_scale=meta["noise_scale"], noise=d("noise"),
+                                        uncond=bool(meta.get("uncond", False)))]
         elif kind == "ttv_gen":
             out = list(mod.inf_plm_gen(d("x_frame"), d("g"), d("codes"), d("frame_lengths"), None))
         elif kind == "plm":

@@ -955,6 +955,38 @@ def test_token_gemm_reads_a_strided_residual_in_place(device):
         conv(torch.randn(1, D, B, generator=g).to(device), res=last(xd))
 
 
+def test_uncond_needs_cfg_and_noise_control_ignores_it(device):
+    """cfg / uncond of SynthesizerTrn (hierspeechpp_speechsynthesizer.py:628-633): a model built without cfg has no null
+    embedding (the reference raises AttributeError on self.emb); voice_conversion_noise_control evaluates the null
+    embedding but conditions on the interpolated style vector all the same (:693-698), so uncond changes nothing there.
+    voice_conversion(uncond=True) itself is the golden `vc_uncond`."""
+    import pytest as _pt
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
+    from oracle import hsp_oracle as O
+    cfg = O.default_config()
+    inp = synth.synth_inputs(1, 24, seed=5, mel_frames=30)
+    d = lambda k: torch.from_numpy(inp[k]).to(device)
+    one = lambda n: torch.tensor([n], dtype=torch.int64, device=device)
+    plain = SynthesizerTrn(641, 61440 // 320, **cfg)
+    plain.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 3)) for k, v in plain.state_dict().items()})
+    with _pt.raises(AttributeError):
+        plain.to(device).voice_conversion(d("w2v"), one(24), d("mel"), one(30), d("f0"), uncond=True, noise=d("noise"))
+    net = SynthesizerTrn(641, 61440 // 320, cfg=True, **cfg)
+    assert "emb.weight" in net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 3)) for k, v in net.state_dict().items()})
+    net.to(device)
+    mel2 = torch.cat([d("mel"), d("mel").flip(2)])
+    a = net.voice_conversion_noise_control(d("w2v"), one(24), mel2, torch.tensor([30, 30], device=device), d("f0"),
+                                           denoise_ratio=0.4, noise=d("noise"))
+    b = net.voice_conversion_noise_control(d("w2v"), one(24), mel2, torch.tensor([30, 30], device=device), d("f0"),
+                                           denoise_ratio=0.4, noise=d("noise"), uncond=True)
+    assert torch.equal(a, b)
+    c = net.voice_conversion(d("w2v"), one(24), d("mel"), one(30), d("f0"), noise=d("noise"))
+    u = net.voice_conversion(d("w2v"), one(24), d("mel"), one(30), d("f0"), noise=d("noise"), uncond=True)
+    assert float((c - u).abs().max()) > 1e-3      # the null embedding really replaces the style vector
+
+
 def test_second_output_gemm_matches_two_launches(device):
     """hsp_conv1d_args.split_row: one token-GEMM launch for the two row halves of a WN res_skip layer
     (modules.py:166-174) == the two separate launches, bit for bit; shapes without a fused kernel are refused

@@ -400,11 +400,38 @@ def denoiser_cases():
              dict(wav=wav, amp_in=a_in.numpy(), pha_in=p_in.numpy()), [audio, amp], [o_audio, o_amp])
 
 
+def cfg_cases():
+    """voice_conversion(uncond=True) of a model built with cfg=True (hierspeechpp_speechsynthesizer.py:628-633,669-671).
+    The reference's constructor moves its index tensor with ``.cuda()``; this container has no GPU, so Tensor.cuda is the
+    identity while the model is built (nothing else of the reference is touched)."""
+    import hierspeechpp_speechsynthesizer as H
+    cfg = O.default_config()
+    W = 7
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        net = H.SynthesizerTrn(641, 61440 // 320, cfg=True, **{k: v for k, v in cfg.items() if k != "gin_channels"})
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    shapes, sd = load_synth(net, W, "")
+    used = [(k, s) for k, s in shapes if k.split(".")[0] in ("emb_g", "enc_p_l", "flow_l", "flow", "sn", "dec", "emb")]
+    name = "vc_uncond"
+    inp = synth.synth_inputs(2, 33, seed=96, mel_frames=41)
+    slen, mlen1 = np.array([33, 27], np.int64), np.array([41, 30], np.int64)
+    f0 = inp["f0"]
+    with FixedNoise(t(inp["noise"])):
+        ref = net.voice_conversion(t(inp["w2v"]), t(slen), t(inp["mel"]), t(mlen1), t(f0), noise_scale=0.333, uncond=True)
+    orc = O.synth_voice_conversion(sd, cfg, t(inp["w2v"]), t(slen), t(inp["mel"]), t(mlen1), t(f0), 0.333, t(inp["noise"]),
+                                   uncond=True)
+    save(name, dict(kind="vc_plain", prefix="", seed=W, shapes=used, noise_scale=0.333, uncond=True, cfg=True),
+         dict(w2v=inp["w2v"], f0=f0, mel=inp["mel"], noise=inp["noise"], src_length=slen, trg_length=mlen1), ref, orc)
+
+
 # ----------------------------------------------------------------------------- cases
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv", "w2v", "denoiser"],
+    ap.add_argument("--group", default="all", choices=["all", "vocoder", "ttv", "w2v", "denoiser", "cfg"],
                     help="vocoder: hierspeechpp/attentions/speechsr cases; ttv: ttv_v1 front-end + PLM cases; "
                          "w2v: the wav2vec2 producer of inference_vc.py; denoiser: the MP-SENet prompt denoiser")
     args = ap.parse_args()
@@ -427,6 +454,11 @@ def main():
         with torch.no_grad():
             ttv_cases()
     if args.group == "ttv":
+        return
+    if args.group in ("all", "cfg"):
+        with torch.no_grad():
+            cfg_cases()
+    if args.group == "cfg":
         return
     import hierspeechpp_speechsynthesizer as H
     import modules as M
