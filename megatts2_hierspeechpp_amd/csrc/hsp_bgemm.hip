@@ -1,28 +1,33 @@
 // Throughput-oriented fp32-MFMA GEMM for the LARGER token matrices of the 50 Hz part:
-//   Y[M x N] = epilogue(W[M x K] X[K x N]),  a few thousand columns, M of several hundred rows
-// (the PLM loop beyond ~60 prefix positions: K = 276, M = 828 / 1104, N = 16 n; reference call sites
-// ttv_v1/transformer_mega.py:63-73 (w_q / w_k / w_v), :121-126 (ff.0)).
+//   Y[M x N] = epilogue(W[M x K] X[K x N]),  from ~96 tiles of 64 x 64 outputs per launch upward
+// (the PLM loop beyond ~30 prefix positions: K = 276 / 1104, M = 276 / 828 / 1104, N = 16 n -- reference call sites
+// ttv_v1/transformer_mega.py:63-73 (w_q / w_k / w_v, out_proj), :121-126 (ff.0, ff.3); the DiT qkv / proj / fc2 and WN
+// res_skip 1x1s of a front group of the vocoder, modules.py:166-174,357-411).
 //
-// Why a third token-GEMM kernel.  hsp_rgemm.hip (no staging, 32 x 32 / 64 x 32 tiles) and hsp_tokgemm.hip
-// (LDS-DMA, 64 x 64 tiles) are built around the latency of a launch; at 1 600-3 200 columns they move 8-16 flop per
-// byte through the L2 -> CU paths (900 tiles x 141 KB = 127 MB for the 1104 x 3200 x 276 product) and sit at 35-40
-// TFLOP/s whatever the MFMA rate is.  Here ONE tile per CU is the aim: 128 x 128 (or 128 x 64 / 64 x 128) outputs per
-// workgroup, chosen so that the launch has about as many tiles as the chip has CUs -- 32 flop per byte, half the
-// traffic, and a consumer wave owns a 2 x 2 grid of 32 x 32 MFMA blocks, so that one LDS fragment feeds two MFMAs.
+// Why a third token-GEMM kernel.  hsp_rgemm.hip (no staging, 32 x 32 / 64 x 32 tiles, K split over the waves) and
+// hsp_tokgemm.hip (LDS-DMA, 64 x 64 tiles) are built around the latency of ONE small launch; at 1 600-3 200 columns they
+// sat at 35-40 TFLOP/s, and their fused input LayerNorm took its statistics on the producers' critical path (+14 us at
+// 3 200 columns).  Two tile shapes here (hsp_bgemm_try picks; tools/gemm_bench.py, profiles/r03_bgemm_bench.txt):
+//   64 x 64   three 48-channel stages = 72 KB of LDS -> TWO workgroups per CU: the second resident tile covers the
+//             first one's start (1.2 us to the first stage) and its epilogue; the default;
+//   128 x 128 one workgroup per CU, half the L2 traffic per flop; from ~850 small tiles (1104 x 3 200).
+// (128 x 64 and 64 x 128 exist in the tuning build only: ties.)
 //
-//   waves 0-3  consumers (2 x 2 over the tile): read A / B fragments from LDS one group of two k-steps ahead of
-//              the MFMAs that use them; with a fused input LayerNorm they also form the column statistics from the B
-//              fragments passing through their registers (pivot-shifted sums, as in the other two kernels) -- no
-//              extra pass over the staged tile and no work on the producers' critical path;
-//   waves 4-7  producers: LDS-DMA only, 48-channel stages, three (128 x 128) or four stages in flight.
+//   waves 0-3  consumers (2 x 2 over the tile, TM x TN blocks of 32 x 32 each): A / B fragments by plain LDS loads one
+//              group of k-steps ahead of the MFMAs that use them (the compiler counts them and places the waits; a
+//              scheduling barrier per group keeps the order); with a fused input LayerNorm they also form the column
+//              statistics from the B fragments passing through their registers (pivot-shifted sums, as in the other two
+//              kernels) -- no extra pass over the staged tile and no work on the producers' critical path;
+//   waves 4-7  producers: LDS-DMA only, three (four: 128 x 64) stages in flight; one vector instruction per DMA on
+//              interior tiles (lane offset once per tile, the row walked by the scalar unit).
 //
 // Workgroup order is XCD-aware: the row tiles of one column tile get consecutive logical ids and an XCD takes a
 // contiguous range of ids, so a column tile's activations are fetched into ONE L2 and reused there by its row tiles.
 //
 // Operands as in hsp_tokgemm.hip: W packed [K][w_ld], X channel-major with unit column stride and 16-B addressable
-// rows; out-of-range 16-B lane groups read the zero buffer.  Epilogue: the same operation order as the other
-// token-GEMM kernels (bias + conditioning bias, LayerNorm correction, pointwise function, masks, per-(b, c) scale,
-// scale, residual, accumulate, post_scale).
+// rows; out-of-range 16-B lane groups read the zero buffer.  Epilogues (bg_epilogue, bg_epilogue_ext): the operation
+// order of the other token-GEMM kernels (bias + conditioning bias, LayerNorm correction, pointwise function, masks,
+// per-(b, c) scale, scale, residual, accumulate, post_scale), with a compile-time pointwise function.
 #include "hsp_device.h"
 
 #ifdef HSP_TUNING
