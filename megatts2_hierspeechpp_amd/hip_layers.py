@@ -421,6 +421,12 @@ class Conv1d(_ConvBase):
             assert not force_direct and row_range is None
         direct = (force_direct or self.stride != 1 or self.cin < 8 or cout < 8 or Lout < 8 or silu_in) \
             and not gated and act1d is None and self.__dict__.get("_pre_norm") is None
+        if direct and a.res_ts > 1:
+            # the VALU kernel reads its residual at unit column stride (hsp_conv1d_args.res_ts is the register-path
+            # token GEMM's): gather it first -- e.g. the PLM's last layer at B = 4, whose [D, 4] product is below the MFMA path
+            from . import functional as Fh
+            res = Fh.copy_strided(res)
+            a.res, a.res_bs, a.res_cs, a.res_ts = L.fptr(res), res.stride(0), res.stride(1), 0
         rows_full = cout * (2 if gated else 1)
         flops = 2 * B * rows_full * Cin * self.k * Lout
         # algorithmic traffic: input once, output once (+ residual / accumulate reads), weights once

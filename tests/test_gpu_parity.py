@@ -931,6 +931,20 @@ def test_block_token_gemm_second_output(device):
         _close(both[1].cpu().numpy(), (prev.cpu() + full[:, H_:]).numpy(), "bgemm split: second output vs torch")
 
 
+def test_plm_small_batches_match_single_rows(device):
+    """Megatts2PLM1.infer at B = 4 and B = 8 (the last layer's [D, B] launches fall below / onto the MFMA path; its residual
+    is the strided last position of the layer input) against the same rows run one at a time."""
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import Megatts2PLM1
+    m = Megatts2PLM1()
+    m.load_state_dict({k: torch.from_numpy(synth.synth_tensor("plm." + k, tuple(v.shape), 7)) for k, v in m.state_dict().items()})
+    m.to(device)
+    tc = torch.from_numpy(np.random.default_rng(4).standard_normal((8, 256, 14)).astype(np.float32)).to(device)
+    single = torch.cat([m.infer(tc[b:b + 1]) for b in range(8)])
+    assert torch.equal(m.infer(tc[:4]), single[:4])
+    assert torch.equal(m.infer(tc), single)
+
+
 def test_token_gemm_reads_a_strided_residual_in_place(device):
     """hsp_conv1d_args.res_ts: the last layer of the PLM loop adds the LAST position of every utterance (columns T-1,
     2T-1, ... of the layer input) to a [D, B] product without a gather launch; other kernels refuse such a residual."""
