@@ -902,6 +902,98 @@ def test_block_token_gemm_vs_torch(cin, cout, N, B, flags, device):
     _close(got, ref.numpy(), f"bgemm {cin}->{cout} N={N} B={B} {flags}")
 
 
+def test_block_token_gemm_random_shapes(device):
+    """Seeded sweep of the block token GEMM over odd sizes (K, M, N multiples of 4 only; batches; every epilogue flag at
+    random) against torch on the CPU: edge tiles in both directions, K tails, the extended epilogue's row bookkeeping."""
+    import ctypes as C
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import hip_layers
+    from megatts2_hierspeechpp_amd.ttv_v1.transformer_mega import LayerNorm
+    rng = np.random.default_rng(2024)
+    taken = 0
+    for case in range(24):
+        cin = int(rng.integers(24, 300)) * 4
+        cout = int(rng.integers(16, 300)) * 4
+        N = int(rng.integers(1, 150)) * 4
+        B = int(rng.integers(1, 10))
+        if ((cout + 63) // 64) * ((N + 63) // 64) * B < 96:
+            B = -(-96 // (((cout + 63) // 64) * ((N + 63) // 64)))
+        ln = bool(rng.integers(0, 2))
+        ext = (not ln) and bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(1000 + case)
+        lin, norm = hip_layers.LinearCT(cin, cout), LayerNorm(cin)
+        w, bias = torch.randn(cout, cin, generator=g) / cin ** 0.5, 0.1 * torch.randn(cout, generator=g)
+        gamma, beta = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+        lin.weight.data, lin.bias.data, norm.weight.data, norm.bias.data = w.clone(), bias.clone(), gamma.clone(), beta.clone()
+        if ln:
+            lin.fuse_input_layernorm(norm)
+        hip_layers.finalize(torch.nn.ModuleList([norm, lin]), device)
+        x = 1.5 * torch.randn(B, cin, N, generator=g) + 0.7
+        xin = torch.nn.functional.layer_norm(x.transpose(1, 2), (cin,), gamma, beta, 1e-5).transpose(1, 2) if ln else x
+        ref = torch.nn.functional.conv1d(xin, w[:, :, None], bias)
+        kw = {}
+        act = int(rng.integers(0, 3))
+        if act == 1:
+            ref, kw["act"] = torch.relu(ref), L.ACT_RELU
+        elif act == 2:
+            ref, kw["act"] = torch.nn.functional.gelu(ref, approximate="tanh"), L.ACT_GELU_TANH
+        if ext:
+            mask = (torch.rand(B, 1, N, generator=g) > 0.3).float()
+            cs = torch.randn(B, cout, generator=g)
+            ref = ref * mask * cs[:, :, None] * 0.75
+            kw.update(mask=mask.to(device), mask_mode=L.MASK_PRE, cscale=cs.to(device), scale=0.75)
+        if bool(rng.integers(0, 2)):
+            res = torch.randn(B, cout, N, generator=g)
+            ref = ref + res
+            kw["res"] = res.to(device)
+        if ext and bool(rng.integers(0, 2)):
+            y0 = torch.randn(B, cout, N, generator=g)
+            ref = (ref + y0) * 0.5
+            kw.update(out=y0.clone().to(device), accumulate=True, post_scale=0.5)
+        plans = []
+
+        def hook(kind, flops, nbytes, e0, e1, la):
+            plan = (C.c_int32 * 4)()
+            L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
+            plans.append(tuple(plan))
+
+        hip_layers.LAUNCH_HOOK = hook
+        try:
+            got = lin(x.to(device), **kw).cpu().numpy()
+        finally:
+            hip_layers.LAUNCH_HOOK = None
+        taken += plans[0][2] == -2
+        _close(got, ref.numpy(), f"case {case}: {cin}->{cout} N={N} B={B} ln={ln} ext={ext} act={act} plan={plans[0]}")
+    assert taken >= 20, f"only {taken} of 24 cases reached the block token GEMM"
+
+
+def test_plm_embed_step_equals_argmax_then_embed(device):
+    """hsp_plm_embed_step_f32 (the greedy choice of the previous step folded into the embedding launch) against
+    hsp_argmax_f32 followed by hsp_plm_embed_f32, bit for bit, with ties in the logits (first maximal index wins)."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.ttv_v1.t2w2v_transformer import Megatts2PLM1
+    m = Megatts2PLM1()
+    m.load_state_dict({k: torch.from_numpy(synth.synth_tensor("plm." + k, tuple(v.shape), 7)) for k, v in m.state_dict().items()})
+    m.to(device)
+    g = torch.Generator().manual_seed(8)
+    for B, n in [(16, 2), (5, 37), (32, 200)]:
+        tc = torch.randn(B, 256, 200, generator=g).to(device)
+        codes = torch.randint(0, 1024, (B, 201), generator=g).to(device)
+        codes[:, 0] = m.GO_ID
+        logits = torch.randn(1, 1024, B, generator=g)
+        logits[0, 100, :] = logits[0, 900, :] = 9.0            # a tie between two indices: 100 must win
+        logits = logits.to(device)
+        m.infer(tc[:1, :, :2])                                 # packs the weights (first use)
+        c1, c2 = codes.clone(), codes.clone()
+        L.check(L.lib().hsp_argmax_f32(L.fptr(logits), 1, B, B, 1024, L.ptr(c1[:, n - 1:]), c1.stride(0), L.stream_ptr()),
+                "hsp_argmax_f32")
+        x1 = m._embed(tc, c1, n)
+        x2 = m._embed(tc, c2, n, prev_logits=logits)
+        assert torch.equal(c1, c2) and bool((c2[:, n - 1] == 100).all())
+        assert torch.equal(x1, x2)
+
+
 def test_block_token_gemm_second_output(device):
     """hsp_conv1d_args.split_row on the block token GEMM (WN res_skip layer of a whole front group: rows [0, H) ->
     x + res_skip * mask, rows [H, 2H) -> running skip sum) against the two single-output launches."""
