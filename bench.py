@@ -57,6 +57,12 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (global batch = batch x gpus)")
     ap.add_argument("--seconds", type=float, default=4.0, help="audio seconds per utterance")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="utterances of the whole job (default batch x gpus); need not divide by the rank count: "
+                         "parallel.shard_range hands out contiguous shards whose sizes differ by at most one")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="form the RCCL process group and run every collective of the N > 1 path (weight broadcast, "
+                         "barriers, timing reductions) at world size 1 as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2] and configs[3])")
@@ -163,7 +169,8 @@ def run_bench(args, make_workload, backend="nccl", device=None):
     import torch.distributed as dist
     from megatts2_hierspeechpp_amd import parallel
 
-    rank, local_rank, world = parallel.init_distributed(backend)
+    rank, local_rank, world = parallel.init_distributed(backend, force=getattr(args, "force_dist", False))
+    coll = parallel.collectives_on()      # N > 1, or --force-dist: the collectives of the multi-GPU path run
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dev = device if device is not None else torch.device("cuda", local_rank)
@@ -175,7 +182,7 @@ def run_bench(args, make_workload, backend="nccl", device=None):
     wl = make_workload(args, rank, world, dev)
     # weights: rank 0 folds + packs, everyone else lays the same arena out; one chunked broadcast
     sync()
-    if world > 1:
+    if coll:
         dist.barrier()
     tm = {}
     arena = parallel.finalize_distributed(wl.model, dev, src=0, timings=tm)
@@ -185,14 +192,15 @@ def run_bench(args, make_workload, backend="nccl", device=None):
     pack_ms = parallel.gather_floats(tm["pack_ms"], dev)[0]
     broadcast_ms = parallel.barrier_max(tm["broadcast_ms"], dev) if tm["broadcast_ms"] is not None else None
 
-    lo, hi = parallel.shard_range(args.batch * world, rank, world)
+    n_utt = args.global_batch if getattr(args, "global_batch", None) else args.batch * world
+    lo, hi = parallel.shard_range(n_utt, rank, world)
     wl.prepare(lo, hi)
     step = wl.make_step()
 
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if coll:
         dist.barrier()
     sync()
     events = []
@@ -207,14 +215,13 @@ def run_bench(args, make_workload, backend="nccl", device=None):
             events.append((e0, e1))
     sync()
     local = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         dist.barrier()
     sync()
     elapsed = parallel.barrier_max(time.perf_counter() - t0, dev)
     per_rank = parallel.gather_floats(1e3 * local / args.steps, dev)
     wl.check(out)
 
-    n_utt = args.batch * world
     samples_per_step = n_utt * wl.samples_per_utterance
     audio_s_per_step = samples_per_step / 16000.0
     result = None
@@ -222,6 +229,7 @@ def run_bench(args, make_workload, backend="nccl", device=None):
         cfg = wl.describe(world)
         cfg["weights_mb"] = arena.buffer.numel() * 4 / 1e6
         cfg["shard_of_rank0"] = [lo, hi]
+        cfg["global_batch"] = n_utt
         result = {
             "metric": METRIC, "value": samples_per_step * args.steps / elapsed, "unit": "samples/s",
             "rtf": (elapsed / args.steps) / audio_s_per_step, "n_gpus": world, "steps": args.steps,
@@ -230,7 +238,7 @@ def run_bench(args, make_workload, backend="nccl", device=None):
             "pack_ms": pack_ms, "broadcast_ms": broadcast_ms,
             "broadcast_gbs": (arena.buffer.numel() * 4 / 1e9) / (broadcast_ms * 1e-3) if broadcast_ms else None,
             "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)},
-            "rccl_world": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend if world > 1 else None,
+            "rccl_world": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend if coll else None,
         }
         if events:
             import numpy as np

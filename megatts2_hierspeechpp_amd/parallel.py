@@ -20,10 +20,24 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_distributed(backend: str = "nccl"):
-    """backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
+# When True, a world-size-1 job still forms its process group and runs every collective of the N > 1 path (the weight
+# broadcast, the timing reductions): `bench.py --gpus 1 --force-dist` and the one-GPU RCCL test set it, so that the code
+# the 8-GPU run depends on has executed on a device before the day a node is available.
+FORCE_COLLECTIVES = False
+
+
+def collectives_on() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+def init_distributed(backend: str = "nccl", force: bool = False):
+    """backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  ``force``: form the group at world size 1
+    too (and keep every collective of the N > 1 path switched on, see FORCE_COLLECTIVES)."""
+    global FORCE_COLLECTIVES
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if force:
+        FORCE_COLLECTIVES = True
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -42,26 +56,32 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20) -> torch.Tensor:
+def broadcast_buffer(buf: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20, force: bool = False) -> torch.Tensor:
     """Broadcast one flat buffer in large chunks (xGMI is point-to-point: few, large
     transfers; 256 MiB chunks keep RCCL's ring pipelined without a huge staging need)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_on() or (force and dist.is_initialized()):
         flat = buf.view(-1)
         for off in range(0, flat.numel(), chunk_elems):
             dist.broadcast(flat[off:off + chunk_elems], src=src)
     return buf
 
 
-def finalize_distributed(model, device, src: int = 0, timings: dict = None):
+def barrier() -> None:
+    if collectives_on():
+        dist.barrier()
+
+
+def finalize_distributed(model, device, src: int = 0, timings: dict = None, force_collective: bool = False):
     """Rank ``src`` folds + packs the weights; every other rank only lays the arena out
     (identical offsets by construction) and receives the bytes by broadcast.
 
     ``timings`` (optional dict) receives ``pack_ms`` -- this rank's fold + pack + upload (or arena layout) -- and
     ``broadcast_ms`` -- the ``dist.broadcast`` loop alone, bracketed by a barrier and device synchronisation on both
     sides so that it starts when the slowest rank is ready and ends when the last byte has landed; ``None`` at
-    world size 1 (no collective runs)."""
+    world size 1 (no collective runs) unless ``force_collective`` / FORCE_COLLECTIVES asks for the broadcast branch on
+    a one-rank group (the process group must exist: ``init_distributed(force=True)``)."""
     import time
-    multi = dist.is_initialized() and dist.get_world_size() > 1
+    multi = collectives_on() or (force_collective and dist.is_initialized())
     on_gpu = torch.device(device).type == "cuda"
     sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -79,7 +99,7 @@ def finalize_distributed(model, device, src: int = 0, timings: dict = None):
         dist.barrier()
         sync()
         t0 = time.perf_counter()
-        broadcast_buffer(arena.buffer, src)
+        broadcast_buffer(arena.buffer, src, force=True)
         sync()
         dist.barrier()
         bc_ms = 1e3 * (time.perf_counter() - t0)
@@ -90,7 +110,7 @@ def finalize_distributed(model, device, src: int = 0, timings: dict = None):
 
 def barrier_max(value: float, device) -> float:
     """max over ranks of a python float (timing reduction of bench.py)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not collectives_on():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -99,7 +119,7 @@ def barrier_max(value: float, device) -> float:
 
 def gather_floats(value: float, device) -> list:
     """every rank's python float, in rank order (per-rank spread of bench.py's step time)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not collectives_on():
         return [value]
     t = torch.tensor([value], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]

@@ -51,7 +51,7 @@ def test_golden_through_the_fused_two_gemm_kernel(name, device, monkeypatch):
         _close(o, r, f"{name}[{i}] (fused)")
 
 
-@pytest.mark.parametrize("name", ["infer_config1", "vc_noise_control", "tts_e2e", "plm_t12", "speechsr48", "speechsr24_real",
+@pytest.mark.parametrize("name", ["infer_config1", "vc_noise_control", "tts_e2e", "plm_t12", "speechsr48", "speechsr24_real", "speechsr48_real",
                                   "ttv_front_n12", "denoise_l8000", "w2v_hidden7_t25", "generator"])
 def test_drop_in_call_sequence(name, device):
     """INTEGRATION.md's snippet with only the import line changed: ``Model(...).cuda()`` -> ``load_state_dict`` ->
@@ -416,6 +416,47 @@ def test_full_size_one_utterance_vs_oracle(full_model, device):
         go, ge = full_model.infer(*(t[k].to(device) for k in ("mel", "w2v", "length", "f0")), noise=t["noise"].to(device))
     _close(go.cpu().numpy(), ro.numpy(), "infer 1x4s audio")
     _close(ge.cpu().numpy(), re_.numpy(), "infer 1x4s source")
+
+
+def test_rccl_world1_on_device(device):
+    """configs[4]'s collective code on a real device: a fresh child process -- started as a
+    subprocess, never a re-exec -- forms a world-size-1 RCCL group with device_id=cuda:0, forces finalize_distributed
+    through its broadcast branch, runs barrier_max / gather_floats on device tensors, captures and replays the step's
+    hipGraph AFTER the collectives, broadcasts again after the replay, and meets the golden `infer_config1`
+    (tests/rccl_world1_child.py; reference: inference_plm.py:336-339 has no collective at all, train_ms.py:106 is its
+    only NCCL init)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(here, "rccl_world1_child.py")], capture_output=True, text=True,
+                       timeout=420, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl_world"] == 1 and line["backend"] == "nccl" and line["broadcast_ms"] > 0
+    assert all(e <= t for e, t in zip(line["eager_err"], line["tol"])), line
+    assert all(e <= t for e, t in zip(line["replay_err"], line["tol"])), line
+
+
+def test_bench_force_dist_line_on_device(device):
+    """`python bench.py --gpus 1 --force-dist` (small workload): the driver-format line of a run whose process group,
+    weight broadcast, barriers and timing reductions all went through RCCL on the device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3",
+                        "--warmup", "1", "--batch", "2", "--seconds", "1", "--no-cpu-baseline", "--no-extra",
+                        "--no-roofline"], capture_output=True, text=True, timeout=420, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line["rccl_world"] == 1 and line["backend"] == "nccl" and line["n_gpus"] == 1
+    assert line["broadcast_ms"] > 0 and line["broadcast_gbs"] > 0 and line["pack_ms"] > 0
+    assert line["config"]["shard_of_rank0"] == [0, 2] and line["value"] > 0
 
 
 def test_layout_only_rank_reproduces_rank0(device):

@@ -12,6 +12,7 @@ import socket
 import subprocess
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -137,6 +138,78 @@ def test_bench_control_flow_world2_cpu_stand_in():
     assert line["pack_ms"] > 0 and line["broadcast_gbs"] > 0       # the collective alone, apart from the packing
     # whole-job value: the units ALL ranks processed over the max-over-ranks time
     assert abs(line["value"] - 14 * 1000 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    json.dumps(line)
+
+
+def _force_worker(port, out):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import bench
+    from megatts2_hierspeechpp_amd import parallel
+    args = bench.parse_args(["--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--batch", "5"])
+    result, wl = bench.run_bench(args, _StandInWorkload, backend="gloo", device=torch.device("cpu"))
+    out.put((result, wl.shard, parallel.collectives_on(), dist.is_initialized()))
+    dist.destroy_process_group()
+
+
+def test_force_dist_runs_the_collectives_at_world_size_1():
+    """`--force-dist`: the one-rank job forms its process group and goes through the broadcast branch, the barriers and
+    the timing reductions (the GPU twin of this test runs it over RCCL on the device)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(_free_port(), q))
+    p.start()
+    line, shard, coll, init = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and coll and init and shard == (0, 5)
+    assert line["rccl_world"] == 1 and line["backend"] == "gloo" and line["broadcast_ms"] > 0 and line["broadcast_gbs"] > 0
+
+
+def _bench_worker8(rank, world, port, out, global_batch):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    import bench
+    argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "32"]
+    if global_batch is not None:
+        argv += ["--global-batch", str(global_batch)]
+    args = bench.parse_args(argv)
+    result, wl = bench.run_bench(args, _StandInWorkload, backend="gloo", device=torch.device("cpu"))
+    out.put((rank, result, wl.shard))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [None, 250])
+def test_bench_control_flow_world8_cpu_stand_in(global_batch):
+    """BASELINE.json configs[4]'s shape -- 8 ranks, 256 utterances, 32 per rank -- through bench.run_bench on gloo
+    (VERDICT r03 item 1b), and an uneven global batch of 250 (shards of 32 / 32 / 31 x 6): every rank's shard is
+    contiguous, the shards tile the batch, `value` counts what ALL ranks processed."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker8, args=(r, world, port, q, global_batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    total = 256 if global_batch is None else global_batch
+    shards = [sh for _, _, sh in res]
+    assert shards[0][0] == 0 and shards[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(shards, shards[1:]))            # contiguous, no gap, no overlap
+    sizes = [hi - lo for lo, hi in shards]
+    assert max(sizes) - min(sizes) <= 1 and (sizes == [32] * 8 if global_batch is None else sizes == [32, 32] + [31] * 6)
+    lines = [r for _, r, _ in res]
+    assert lines[0] is not None and all(ln is None for ln in lines[1:])     # only rank 0 reports
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["rccl_world"] == 8 and line["backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["config"]["shard_of_rank0"] == [0, 32] and line["config"]["global_batch"] == total
+    assert line["broadcast_ms"] > 0 and line["pack_ms"] > 0
+    assert abs(line["value"] - total * 1000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
     json.dumps(line)
 
 

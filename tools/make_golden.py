@@ -654,6 +654,15 @@ def main():
         err = (net_sr(t(x)) - O.speechsr(real, t(x), 3, "dec")).abs().max().item()
         print(f"speechsr48 real checkpoint: oracle-vs-ref {err:.2e}")
         assert err < 1e-4
+        # round 4: the shipped 48 kHz checkpoint's dec.* tensors (data) travel inside a fixture as well, exactly as
+        # speechsr24_real's do, so that the GPU parity test runs the HIP path on the REAL weights of configs[3]'s network
+        # (speechsr48k/speechsr.py:89-109,243-246; the oracle's fp32 floor there is 2.9e-5 -- the narrowest margin of any case)
+        dec48 = {k: v.float() for k, v in real.items() if k.startswith("dec.")}
+        arrays48 = {"x": x}
+        arrays48.update({"w:" + k: v.numpy() for k, v in dec48.items()})
+        save("speechsr48_real", dict(kind="speechsr_real", prefix="", seed=W, shapes=[], factor=3,
+                                     checkpoint="speechsr48k/G_100000.pth (dec.* tensors stored in this fixture)"),
+             arrays48, net_sr(t(x)), O.speechsr(dec48, t(x), 3, "dec"))
 
         # -- N3: SpeechSR24 (speechsr24k/speechsr.py: the same network, interpolation x1.5).  Synthetic weights, and the
         #        REAL shipped checkpoint G_340000.pth: its dec.* tensors (data, 0.43 M floats) travel inside the fixture
