@@ -154,6 +154,26 @@ __device__ __forceinline__ void ds_read_frags_at(float (&f)[N], unsigned addr) {
   }
 }
 
+// The fragment registers written by the asynchronous inline-asm ds_reads above become valid at an s_waitcnt.  The
+// compiler does not know that: nothing but scheduling barriers kept it from moving an MFMA that reads them above a
+// bare `asm volatile("s_waitcnt")` (hsp_bgemm.hip met the failure: stale fragments in some waves).  Here every
+// fragment register is re-defined by an (empty) asm statement right behind the wait -- volatile asm statements keep
+// their order -- so each consumer of a fragment carries a DATA dependency on the wait.  No instruction is emitted
+// for the re-definitions: the ISA of the consumer loop is unchanged.
+template <int N, int I = 0>
+__device__ __forceinline__ void bind_frags(float (&f)[N]) {
+  if constexpr (I < N) {
+    asm volatile("" : "+v"(f[I]));
+    bind_frags<N, I + 1>(f);
+  }
+}
+template <int NA, int NB>
+__device__ __forceinline__ void wait_frags(float (&fa)[NA], float (&fb)[NB]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  bind_frags<NA>(fa);
+  bind_frags<NB>(fb);
+}
+
 // wave-local LDS ordering: all earlier LDS ops of this wave are complete and the
 // compiler may not move memory accesses across this point
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -587,7 +607,7 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
       };
       // first slot of a trip: the second step of the same tap, through immediates
       auto slot_a = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the first step's fragments have landed
+        wait_frags(fa0, fb0);               // the first step's fragments have landed (and only now are they valid)
         __builtin_amdgcn_sched_barrier(0);
         ds_read_frags_at<TM, kStepA>(fa1, va);
         ds_read_frags_at<TN, rowB>(fb1, vb);
@@ -600,7 +620,7 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
         advance();
         va = aA + (unsigned)offA;
         vb = aB + (unsigned)(pairB + tapoff);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the second step's fragments have landed
+        wait_frags(fa1, fb1);               // the second step's fragments have landed
         __builtin_amdgcn_sched_barrier(0);
         ds_read_frags<TM>(fa0, va);
         ds_read_frags<TN>(fb0, vb);
@@ -610,6 +630,8 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
       }
       slot_a();                                    // last trip, first step
       HSP_BARRIER(a);                              // (waits lgkmcnt(0) first) chunk c+1 is staged, chunk c's buffer is free
+      bind_frags<TM>(fa1);                         // the barrier's wait is what makes the last step's fragments valid
+      bind_frags<TN>(fb1);
       if (c + 1 < nchunks) {
         const int nb = (c + 1) & 1;
         aA = lds_addr(lds + nb * P.ws_sz + wlane);

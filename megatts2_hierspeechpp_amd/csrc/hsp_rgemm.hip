@@ -112,7 +112,10 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rgemm_kernel(const hsp_conv1d_a
   auto load = [&](int kk, float (&A)[RG_U], float (&B)[RG_U]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
-      const int k = min(kk + u, kk1 - 1);       // clamped: the surplus steps of the last group are zeroed below
+      int k = min(kk + u, kk1 - 1);             // clamped: the surplus steps of the last group are zeroed below
+      // odd K: the second channel of the last k-step does not exist -- W row K / x channel K would be one row past the
+      // packed weight and the activations.  Read the previous step's (legal) address instead; the value is zeroed below.
+      if (odd_tail && half == 1 && k == ksteps - 1) k -= 1;
       A[u] = wp[(int64_t)k * wst];
       B[u] = xp[(int64_t)k * xst];
     }

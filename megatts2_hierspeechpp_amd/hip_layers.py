@@ -91,7 +91,8 @@ def _launch(kind: str, fn, a, flops: int, nbytes: int, soft: bool = False, keep=
     a.debug = DEBUG_FLAGS
     if _DEFER is not None:
         # the struct holds raw device pointers: `keep` pins the tensors behind them until launch_group() has run
-        assert not soft and not a.ln_c1 and not a.split_row, "deferred(): no soft / fused-LayerNorm / split launches"
+        if soft or a.ln_c1 or a.split_row:    # not an assert: python -O would pass a fused-LayerNorm struct through
+            raise L.HspError("deferred(): no soft / fused-LayerNorm / split launches")
         _DEFER.append((a, flops, nbytes, keep))
         return 0
     if SURVEY_ABI:
@@ -442,7 +443,16 @@ class Conv1d(_ConvBase):
             return None if rc else (out, out2)
         if direct:
             _launch("hsp_conv1d_direct_f32", L.lib().hsp_conv1d_direct_f32, a, flops, nbytes)
-        elif self.__dict__.get("_pre_norm") is not None and _DEFER is None:
+        elif self.__dict__.get("_pre_norm") is not None and _DEFER is not None:
+            # inside deferred(): the normalisation (affine part folded into the packed weights) runs now as its own
+            # launch, the plain GEMM joins the group
+            from . import functional as Fh
+            xn = Fh.layernorm_mod(x, float(self._pre_norm.eps))
+            a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xn), xn.stride(0), xn.stride(1), xn.stride(2)
+            a.ln_c1 = None
+            _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, flops, nbytes,
+                    keep=(xn, out, res, cbias, mask, cscale))
+        elif self.__dict__.get("_pre_norm") is not None:
             # fused input LayerNorm: token-GEMM shapes only (16-B addressable columns).  Any other shape runs the
             # normalisation as its own launch -- WITHOUT the affine part, which is folded into the packed weights
             # (W diag(gamma), W beta + b) -- and then the same GEMM: identical arithmetic, one launch more.
@@ -678,6 +688,8 @@ def _set_epilogue(a, act, cbias, mask, mask_mode, cscale, scale, res, accumulate
         assert res.shape == out.shape
         a.res, a.res_bs, a.res_cs = L.fptr(res), res.stride(0), res.stride(1)
         if res.stride(2) != 1 and res.shape[2] != 1:
+            if res.stride(2) < 1:         # a time-broadcast (.expand) residual: every kernel reads res_ts 0 as unit stride
+                raise L.HspError("residual with time stride %d: materialise it (copy_strided) before the launch" % res.stride(2))
             a.res_ts = res.stride(2)      # hsp_conv1d_args.res_ts: the register-path token GEMM only (else HSP_EINVAL)
     a.accumulate = 1 if accumulate else 0
     a.post_scale = float(post_scale)

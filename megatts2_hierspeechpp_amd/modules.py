@@ -76,9 +76,9 @@ class WN(nn.Module):
             self.cond_layer = Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1, weight_norm=True)
         for i in range(n_layers):
             d = dilation_rate ** i
-            if (kernel_size - 1) * d + 3 > 128:
+            if (kernel_size - 1) * d + 3 > 125:   # include/hsp.h: the wide-pitch gated tile (S64GW) holds a 125-column halo
                 raise L.HspError(f"WN layer {i}: halo (k - 1) * dilation + 3 = {(kernel_size - 1) * d + 3} columns exceeds "
-                                 "the widest window pitch of the gated conv kernel (128)")
+                                 "the widest window of the gated conv kernel (125)")
             self.in_layers.append(Conv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=d,
                                          padding=int((kernel_size * d - d) / 2), weight_norm=True,
                                          rows=L.ROWS_GATE_WN))

@@ -418,6 +418,39 @@ def test_full_size_one_utterance_vs_oracle(full_model, device):
     _close(ge.cpu().numpy(), re_.numpy(), "infer 1x4s source")
 
 
+def test_long_utterances_vs_oracle(full_model, device):
+    """Model-level parity beyond T = 333 frames: `infer` on a ragged pair of 20 s and 14.66 s
+    (T = 1 000 / 733: L = 320 000 tails, 31.25-tile stages x 5, DiT attention past the 256-key short-sequence kernel) and
+    `voice_conversion_noise_control` at T = 600, against the oracle -- the reference has no length limit
+    (hierspeechpp_speechsynthesizer.py:635-651,674-699).  About a minute of CPU."""
+    from megatts2_hierspeechpp_amd import synth
+    from oracle import hsp_oracle as O
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd = {k: v.detach().cpu() for k, v in full_model.state_dict().items()}
+    cfg = O.default_config()
+    inp = synth.synth_inputs(2, 1000, seed=4100)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    t["length"] = torch.tensor([1000, 733], dtype=torch.int64)
+    with torch.no_grad():
+        ro, re_ = O.synth_infer(sd, cfg, t["mel"], t["w2v"], t["length"], t["f0"], t["noise"])
+        go, ge = full_model.infer(*(t[k].to(device) for k in ("mel", "w2v", "length", "f0")), noise=t["noise"].to(device))
+    assert go.shape == (2, 1, 320000)
+    _close(go.cpu().numpy(), ro.numpy(), "infer 20 s / 14.66 s audio")
+    _close(ge.cpu().numpy(), re_.numpy(), "infer 20 s / 14.66 s source")
+
+    inp = synth.synth_inputs(1, 600, seed=4101)
+    mel2 = torch.from_numpy(synth.synth_inputs(2, 450, seed=4102)["mel"])
+    mlen, slen = torch.tensor([450, 377], dtype=torch.int64), torch.tensor([600], dtype=torch.int64)
+    w2v, f0, noise = (torch.from_numpy(inp[k]) for k in ("w2v", "f0", "noise"))
+    f0_2d = f0[:, 0]                                       # [1, 4T] as inference_plm.py:172 passes it
+    with torch.no_grad():
+        rv = O.synth_voice_conversion_noise_control(sd, cfg, w2v, slen, mel2, mlen, f0_2d, 0.333, 0.8, noise)
+        gv = full_model.voice_conversion_noise_control(w2v.to(device), slen.to(device), mel2.to(device), mlen.to(device),
+                                                       f0_2d.to(device), noise_scale=0.333, denoise_ratio=0.8,
+                                                       noise=noise.to(device))
+    _close(gv.cpu().numpy(), rv.numpy(), "voice_conversion_noise_control T = 600")
+
+
 def test_rccl_world1_on_device(device):
     """configs[4]'s collective code on a real device: a fresh child process -- started as a
     subprocess, never a re-exec -- forms a world-size-1 RCCL group with device_id=cuda:0, forces finalize_distributed
@@ -1199,6 +1232,44 @@ def test_fused_layernorm_gemm_vs_torch(device):
     x = 2.0 * torch.randn(1, 192, 18, generator=g) - 0.7
     ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.transpose(1, 2), (192,), gamma, beta, 1e-5), w, b)
     _close(lin(x.to(device)).cpu().numpy(), ref.transpose(1, 2).numpy(), "ln + gemm, unaligned columns")
+
+
+@pytest.mark.parametrize("cin,cout,N,B,ln", [(33, 40, 36, 2, False), (277, 276, 48, 1, True), (69, 100, 7, 3, True),
+                                             (1105, 64, 33, 1, False)])
+def test_register_gemm_odd_input_channels(cin, cout, N, B, ln, device):
+    """an odd Cin leaves the last k-step of rgemm_kernel with one channel.  The lanes that own the
+    missing one must neither use it nor read past the packed weight / the activations (they read the previous step's
+    address and zero the value).  x is allocated exactly -- its last channel ends the tensor -- and checked against
+    torch, with and without the fused input LayerNorm; the route is confirmed to be the register-path kernel."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd import hip_layers
+    from megatts2_hierspeechpp_amd.hip_layers import LinearCT, finalize
+    from megatts2_hierspeechpp_amd.ttv_v1.transformer_mega import LayerNorm
+    g = torch.Generator().manual_seed(cin * 7 + N)
+    norm, lin = LayerNorm(cin), LinearCT(cin, cout)
+    gamma, beta = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+    w, b = torch.randn(cout, cin, generator=g) / cin ** 0.5, 0.1 * torch.randn(cout, generator=g)
+    norm.weight.data, norm.bias.data, lin.weight.data, lin.bias.data = gamma.clone(), beta.clone(), w.clone(), b.clone()
+    if ln:
+        lin.fuse_input_layernorm(norm)
+    finalize(torch.nn.ModuleList([norm, lin]), device)
+    x = 2.0 * torch.randn(B, cin, N, generator=g) + 0.5
+    xin = torch.nn.functional.layer_norm(x.transpose(1, 2), (cin,), gamma, beta, 1e-5) if ln else x.transpose(1, 2)
+    ref = torch.nn.functional.linear(xin, w, b).transpose(1, 2)
+    plans = []
+
+    def hook(kind, flops, nbytes, e0, e1, la):
+        plan = (C.c_int32 * 4)()
+        L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
+        plans.append(tuple(plan))
+
+    hip_layers.LAUNCH_HOOK = hook
+    try:
+        got = lin(x.to(device)).cpu().numpy()
+    finally:
+        hip_layers.LAUNCH_HOOK = None
+    assert plans and plans[-1][2] == -1, f"not the register-path token GEMM: plan {plans}"
+    _close(got, ref.numpy(), f"rgemm odd K {cin}->{cout} N={N} ln={ln}")
 
 
 def test_fused_layernorm_survives_a_large_common_mean(device):
