@@ -592,6 +592,11 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
         continue;
       }
       int offA = 0, pairB = 0, tapoff = 0;  // scalar byte offsets of the current trip
+      // The hazard recogniser wants one COUNTED instruction between the re-definition of the fragments in wait_frags
+      // and the first MFMA that reads them, and it does not count inline asm.  So the scalar walk of a trip sits in its
+      // first slot, followed by the one scalar add hipcc emits itself (window offset = pair + tap), and the two VALU
+      // address adds sit in the second slot behind its wait: no s_nop, and as many instructions per trip as before.
+      int offB = 0;
       auto advance = [&]() __attribute__((always_inline)) {
         int t;
         asm volatile(
@@ -604,11 +609,13 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
             : [oa] "+s"(offA), [pb] "+s"(pairB), [to] "+s"(tapoff), [t] "=&s"(t)
             : [sa] "n"(2 * kStepA), [sb] "n"(2 * rowB), [span] "s"(spanB), [tap] "s"(tapB)
             : "scc");
+        offB = pairB + tapoff;
       };
-      // first slot of a trip: the second step of the same tap, through immediates
-      auto slot_a = [&]() __attribute__((always_inline)) {
+      // first slot of a trip: the second step of the same tap, through immediates (+ the scalar walk to the next trip)
+      auto slot_a = [&](bool walk) __attribute__((always_inline)) {
         wait_frags(fa0, fb0);               // the first step's fragments have landed (and only now are they valid)
         __builtin_amdgcn_sched_barrier(0);
+        if (walk) advance();
         ds_read_frags_at<TM, kStepA>(fa1, va);
         ds_read_frags_at<TN, rowB>(fb1, vb);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (true double buffer)
@@ -616,19 +623,18 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
         __builtin_amdgcn_sched_barrier(0);  // or the MFMAs sink below the next wait, which then follows its reads at once
       };
       for (int s = 0; s + 2 < nsteps; s += 2) {   // every trip but the last
-        slot_a();
-        advance();
-        va = aA + (unsigned)offA;
-        vb = aB + (unsigned)(pairB + tapoff);
+        slot_a(true);
         wait_frags(fa1, fb1);               // the second step's fragments have landed
         __builtin_amdgcn_sched_barrier(0);
+        va = aA + (unsigned)offA;           // two VALU adds behind the wait: counted instructions before the MFMAs
+        vb = aB + (unsigned)offB;
         ds_read_frags<TM>(fa0, va);
         ds_read_frags<TN>(fb0, vb);
         __builtin_amdgcn_sched_barrier(0);
         mma_set(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      slot_a();                                    // last trip, first step
+      slot_a(false);                               // last trip, first step
       HSP_BARRIER(a);                              // (waits lgkmcnt(0) first) chunk c+1 is staged, chunk c's buffer is free
       bind_frags<TM>(fa1);                         // the barrier's wait is what makes the last step's fragments valid
       bind_frags<TN>(fb1);
