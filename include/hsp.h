@@ -297,6 +297,39 @@ typedef struct hsp_mha_args {
   int64_t mask_dense_bs;
 } hsp_mha_args;
 int hsp_mha_f32(const hsp_mha_args* a, void* stream);
+/* Self-attention over ALL heads + the output projection + its epilogue in ONE launch (csrc/hsp_mhaproj.hip):
+ *   o[b, h D + d, i] = sum_j softmax_j(qk_scale q[b, h D + :, i] . k[b, h D + :, j]) v[b, h D + d, j]
+ *   y[b, m, i] = ((sum_c wt[m, c] o[b, c, i] + bias[m]) * mask[b, i]) * cscale[b, m] + res[b, m, i]
+ * = scaled_dot_product_attention + out_proj + the residual add of the Mega-TTS2 PLM layer
+ * (ttv_v1/transformer_mega.py:63-87,121-123: 4 heads x 69) and timm Attention's softmax(q k^T) v + proj followed by
+ * `x + gate_msa * attn(.)` of a DiT block (modules.py:397,409: 2 heads x 96).  No masks inside the softmax, 4 <= Tk <= 256.
+ * q / k / v: element (b, c, t) at base + b * bs + c * cs + t (channel-major; a batch may sit side by side on the columns
+ * of one [C][B * T] matrix: bs = T, cs = row pitch).  wt = the nn.Linear / 1x1-conv weight AS STORED, [M][H D] row-major
+ * with row pitch wt_ld (M == H D).  y / res: element (b, m, i) at base + b * bs + m * cs + i * ts, so that the
+ * "last position of every utterance" form of the PLM's final layer (Tq = 1, q pointing at column T - 1) writes a
+ * [M][B] matrix and reads its residual in place.  mask [B][Tq], cscale [B][M], bias [M], res: optional (NULL).
+ * hsp_mha_proj_supported: 1 when a kernel exists for (H, D, M, Tk) -- otherwise the caller issues hsp_mha_f32 and
+ * the projection as two launches (hsp_mha_proj_f32 returns HSP_EINVAL). */
+typedef struct hsp_mha_proj_args {
+  const float *q, *k, *v;
+  int64_t q_bs, q_cs, k_bs, k_cs, v_bs, v_cs;
+  int32_t B, H, D, Tq, Tk;
+  float qk_scale;
+  const float* wt;
+  int32_t M, wt_ld;
+  const float* bias;
+  const float* mask;
+  int64_t mask_bs;
+  const float* cscale;
+  int64_t cscale_bs;
+  const float* res;
+  int64_t res_bs, res_cs, res_ts;
+  float* y;
+  int64_t y_bs, y_cs, y_ts;
+  int32_t debug; /* must be 0 (tuning build only, as hsp_conv1d_args.debug) */
+} hsp_mha_proj_args;
+int hsp_mha_proj_f32(const hsp_mha_proj_args* a, void* stream);
+int hsp_mha_proj_supported(int32_t H, int32_t D, int32_t M, int32_t Tk);
 /* out[b, c] = sum_t x[b, c, t] / sum_t mask[b, t] : styleencoder.py:83-91 */
 int hsp_masked_mean_f32(const float* x, const float* mask, float* out, int32_t B, int32_t C,
                         int32_t T, void* stream);

@@ -61,6 +61,21 @@ class MhaArgs(C.Structure):
     ]
 
 
+class MhaProjArgs(C.Structure):
+    """Mirror of ``hsp_mha_proj_args``."""
+    _fields_ = [
+        ("q", _fp), ("k", _fp), ("v", _fp),
+        ("q_bs", C.c_int64), ("q_cs", C.c_int64), ("k_bs", C.c_int64), ("k_cs", C.c_int64), ("v_bs", C.c_int64),
+        ("v_cs", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
+        ("qk_scale", C.c_float),
+        ("wt", _fp), ("M", C.c_int32), ("wt_ld", C.c_int32),
+        ("bias", _fp), ("mask", _fp), ("mask_bs", C.c_int64), ("cscale", _fp), ("cscale_bs", C.c_int64),
+        ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64), ("res_ts", C.c_int64),
+        ("y", _fp), ("y_bs", C.c_int64), ("y_cs", C.c_int64), ("y_ts", C.c_int64), ("debug", C.c_int32),
+    ]
+
+
 # symbol -> (restype, argtypes); every symbol include/hsp.h declares
 SIGNATURES = {
     "hsp_version": (C.c_int, []),
@@ -78,6 +93,8 @@ SIGNATURES = {
     "hsp_layernorm_mod_f32": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp, _fp, _fp,
                                         C.c_int64, _fp, _fp, _fp]),
     "hsp_mha_f32": (C.c_int, [C.POINTER(MhaArgs), _fp]),
+    "hsp_mha_proj_f32": (C.c_int, [C.POINTER(MhaProjArgs), _fp]),
+    "hsp_mha_proj_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hsp_masked_mean_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_mask_mul_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_linear_interp_f32": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),

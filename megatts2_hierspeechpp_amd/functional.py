@@ -3,6 +3,7 @@ points of libhsp.so.  No torch arithmetic happens here: every op is one HIP laun
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -120,6 +121,49 @@ def mha(q, k, v, n_heads: int, qk_scale: float, mask_q=None, mask_k=None, rel_k=
         a.window = -(a.window + 1)
     L.check(L.lib().hsp_mha_f32(C.byref(a), L.stream_ptr()), "hsp_mha_f32")
     return o
+
+
+# HSP_FUSE_MHA_PROJ=0: attention and its output projection as two launches again (same-box A/B, tests of both paths)
+FUSE_MHA_PROJ = os.environ.get("HSP_FUSE_MHA_PROJ", "1") == "1"
+
+
+def mha_proj_supported(n_heads: int, head_dim: int, m: int, tk: int) -> bool:
+    return FUSE_MHA_PROJ and bool(L.lib().hsp_mha_proj_supported(n_heads, head_dim, m, tk))
+
+
+def mha_proj(q, k, v, n_heads: int, qk_scale: float, wt, bias=None, mask=None, cscale=None, res=None, out=None):
+    """Attention over all heads + output projection + epilogue in one launch (hsp_mha_proj_f32):
+    y = ((wt @ attention(q, k, v) + bias) * mask) * cscale + res.  q [B, H*D, Tq], k / v [B, H*D, Tk] with unit time
+    stride (strided views as for ``mha``); ``wt`` [M, H*D] row-major (the nn.Linear weight as stored); ``res`` / ``out``
+    [B, M, Tq] with ANY strides; ``mask`` [B, 1, Tq] or [B, Tq]; ``cscale`` [B, M]."""
+    B, HD, Tq = q.shape
+    Tk = k.shape[2]
+    M = wt.shape[0]
+    y = torch.empty(B, M, Tq, dtype=torch.float32, device=q.device) if out is None else out
+    assert y.shape == (B, M, Tq) and wt.shape == (M, HD) and wt.stride(1) == 1
+    for t_, T_ in ((q, Tq), (k, Tk), (v, Tk)):
+        assert (t_.stride(2) == 1 or T_ == 1), "attention operands need unit time stride"
+    a = L.MhaProjArgs()
+    a.q, a.k, a.v = L.fptr(q), L.fptr(k), L.fptr(v)
+    a.q_bs, a.q_cs, a.k_bs, a.k_cs, a.v_bs, a.v_cs = q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1)
+    a.B, a.H, a.D, a.Tq, a.Tk = B, n_heads, HD // n_heads, Tq, Tk
+    a.qk_scale = float(qk_scale)
+    a.wt, a.M, a.wt_ld = L.fptr(wt), M, wt.stride(0)
+    if bias is not None:
+        a.bias = L.fptr(bias)
+    if mask is not None:
+        mk = mask.reshape(B, -1)
+        assert mk.shape[1] == Tq and (mk.stride(1) == 1 or Tq == 1)
+        a.mask, a.mask_bs = L.fptr(mk), mk.stride(0)
+    if cscale is not None:
+        assert cscale.shape[:2] == (B, M) and cscale.stride(1) == 1
+        a.cscale, a.cscale_bs = L.fptr(cscale), cscale.stride(0)
+    if res is not None:
+        assert res.shape == y.shape
+        a.res, a.res_bs, a.res_cs, a.res_ts = L.fptr(res), res.stride(0), res.stride(1), max(res.stride(2), 1)
+    a.y, a.y_bs, a.y_cs, a.y_ts = L.fptr(y), y.stride(0), y.stride(1), max(y.stride(2), 1)
+    L.check(L.lib().hsp_mha_proj_f32(C.byref(a), L.stream_ptr()), "hsp_mha_proj_f32")
+    return y
 
 
 def masked_mean(x, mask):

@@ -337,12 +337,19 @@ class Conv1d(_ConvBase):
         b = (n.bias if hasattr(n, "weight") else n.beta).data
         return g, b
 
+    def keep_rowmajor_weight(self):
+        """Also keep the folded weight as stored -- [cout][cin] row-major -- in the arena (``_wt``): the A operand of
+        the projection inside hsp_mha_proj_f32 (attention + output projection in one launch)."""
+        assert self.k == 1 and self.rows == L.ROWS_PLAIN
+        self.__dict__["_rowmajor"] = True
+
     def hsp_requests(self):
         if self.__dict__.get("_stacked_elsewhere"):   # rows live in a StackedLinearCT: parameters only
             return []
         fused = self.__dict__.get("_pre_norm") is not None
         return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias or fused else []) + \
-            ([("c1", self.cout)] if fused else [])
+            ([("c1", self.cout)] if fused else []) + \
+            ([("wt", self.cout * self.cin)] if self.__dict__.get("_rowmajor") else [])
 
     def hsp_fill(self, arena, materialize):
         if self.__dict__.get("_stacked_elsewhere"):
@@ -351,8 +358,12 @@ class Conv1d(_ConvBase):
         self._w = arena.view(self, "w")
         self._b = arena.view(self, "b") if self.has_bias or fused else None
         self._c1 = arena.view(self, "c1") if fused else None
+        self._wt = arena.view(self, "wt").view(self.cout, self.cin) if self.__dict__.get("_rowmajor") else None
         if materialize:
             w = self._folded()
+            if self._wt is not None:
+                assert not fused
+                self._wt.copy_(w.reshape(self.cout, self.cin))
             if fused:
                 g, beta = self._ln_params()
                 w2 = w.reshape(self.cout, self.cin).double()

@@ -147,6 +147,7 @@ class Attention(nn.Module):
         self.scale = (dim // num_heads) ** -0.5
         self.qkv = Conv1d(dim, dim * 3, 1, bias=qkv_bias, weight_2d=True)
         self.proj = Conv1d(dim, dim, 1, weight_2d=True)
+        self.proj.keep_rowmajor_weight()   # A operand of the projection inside hsp_mha_proj_f32
 
 
 class FFN_Conv(nn.Module):
@@ -189,8 +190,13 @@ class DiTConVBlock(nn.Module):
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = (mod[:, i * C:(i + 1) * C, 0] for i in range(6))
         h = Fh.layernorm_mod(x, 1e-6, mask=x_mask, shift=sh_a, scale=sc_a)
         qkv = self.attn.qkv(h)
-        o = Fh.mha(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale)
-        x = self.attn.proj(o, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_a, res=x)
+        if Fh.mha_proj_supported(self.attn.num_heads, C // self.attn.num_heads, C, x.shape[2]):
+            # attention + proj + `x + gate_msa * (.) * mask` in ONE launch (round 4, csrc/hsp_mhaproj.hip)
+            x = Fh.mha_proj(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale,
+                            self.attn.proj._wt, bias=self.attn.proj._b, mask=x_mask, cscale=g_a, res=x)
+        else:
+            o = Fh.mha(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale)
+            x = self.attn.proj(o, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_a, res=x)
         h = Fh.layernorm_mod(x, 1e-6, shift=sh_m, scale=sc_m)
         # fc1 -> GELU -> fc2 as ONE hsp_ffn_conv_f32 call (one launch where the library has the fused kernel);
         # fc2(y * mask) * mask == (W y + b) * mask for a 1x1 conv and a 0/1 mask

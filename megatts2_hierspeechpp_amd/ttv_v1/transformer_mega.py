@@ -60,6 +60,7 @@ class MultiHeadAttention(nn.Module):
         if pre_norm is not None:
             self.qkv.fuse_input_layernorm(pre_norm)
         self.out_proj = nn.ModuleList([LinearCT(qkv_dim, qkv_dim)])  # nn.Sequential(Linear, Dropout): key "out_proj.0"
+        self.out_proj[0].keep_rowmajor_weight()   # A operand of the projection inside hsp_mha_proj_f32
 
     def forward(self, x, kv=None, mask=None, res=None, batch=None, last_only=False):
         """x [1, D, B*T] -> out_proj(attention) [+ res]; ``last_only`` -> [1, D, B]: only the last
@@ -69,6 +70,22 @@ class MultiHeadAttention(nn.Module):
         D = self.qkv_dim
         B, T = batch if batch is not None else (x.shape[0], x.shape[2])
         qkv = self.qkv(x)
+        if batch is not None and Fh.mha_proj_supported(self.n_heads, self.head_dim, D, T):
+            # ONE launch: attention over all heads of a 16-query tile + out_proj + bias + residual (round 4)
+            per = lambda m: m[:, :B * T].reshape(-1, B, T).permute(1, 0, 2)       # [B, C, T] view of a [C, Np] matrix
+            q, k, v = (per(qkv[0, i * D:(i + 1) * D]) for i in range(3))
+            lin = self.out_proj[0]
+            if last_only:
+                # only the last position of every utterance: y [1, D, B], res [1, D, B] (a strided view of x)
+                y = torch.empty(1, D, B, dtype=torch.float32, device=x.device)
+                as_b = lambda m: m[0].permute(1, 0).unsqueeze(2)                     # [B, D, 1] view of [1, D, B]
+                Fh.mha_proj(q[:, :, T - 1:], k, v, self.n_heads, 1.0 / math.sqrt(self.head_dim), lin._wt, bias=lin._b,
+                            res=None if res is None else as_b(res), out=as_b(y))
+                return y
+            y = torch.empty_like(x) if x.shape[2] == B * T else torch.zeros_like(x)
+            Fh.mha_proj(q, k, v, self.n_heads, 1.0 / math.sqrt(self.head_dim), lin._wt, bias=lin._b,
+                        res=None if res is None else per(res[0]), out=per(y[0]))
+            return y
         # padding columns (odd batch sizes only) must stay finite: they flow through the following GEMMs
         o = torch.empty_like(x) if batch is None or x.shape[2] == B * T else torch.zeros_like(x)
         # [B, C, T] view of a [C, Np] matrix (Np >= B*T: rows may be padded to a multiple of 4 columns)

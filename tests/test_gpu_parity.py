@@ -708,6 +708,70 @@ def test_maskless_short_sequence_attention_vs_torch(B, H, D, Tq, Tk, device):
         _close(per(o).cpu().numpy(), want.numpy(), "strided batch layout")
 
 
+@pytest.mark.parametrize("H,D,B,Tq,Tk,form", [
+    (4, 69, 3, 7, 7, "plm"), (4, 69, 2, 64, 64, "plm"), (4, 69, 4, 101, 101, "plm"), (4, 69, 2, 200, 200, "plm"),
+    (4, 69, 5, 4, 4, "plm"), (4, 69, 3, 65, 65, "plm"), (4, 69, 2, 130, 130, "plm"), (4, 69, 1, 256, 256, "plm"),
+    (4, 69, 4, 1, 37, "last"), (4, 69, 16, 1, 200, "last"), (4, 69, 3, 1, 66, "last"),
+    (2, 96, 2, 200, 200, "dit"), (2, 96, 3, 50, 50, "dit"), (2, 96, 1, 133, 133, "dit"), (2, 96, 2, 16, 16, "dit"),
+    (2, 96, 1, 255, 255, "dit"), (2, 96, 1, 1000, 1000, "dit"), (2, 96, 2, 733, 733, "dit"), (4, 69, 2, 333, 333, "plm"),
+    (4, 69, 3, 1, 515, "last"),
+])
+def test_fused_attention_projection_vs_torch(H, D, B, Tq, Tk, form, device):
+    """hsp_mha_proj_f32 (attention over all heads + output projection + epilogue, one launch) against torch fp32 on
+    the CPU, in the three forms the product path issues: the PLM layer (utterances side by side on the columns of one
+    [C, B*T] matrix, bias + residual: transformer_mega.py:63-87,121-123), its last layer (one query per utterance, output
+    [C, B], residual read in place at column stride T) and the DiT block (batch-major tensors, mask, adaLN gate and
+    residual: modules.py:397,409).  Key counts on and off the 4-column and 64-key group boundaries."""
+    from megatts2_hierspeechpp_amd import functional as Fh
+    C_ = H * D
+    g = torch.Generator().manual_seed(1000 * H + 10 * Tk + B)
+    wt, bias = torch.randn(C_, C_, generator=g) / C_ ** 0.5, 0.1 * torch.randn(C_, generator=g)
+    scale = D ** -0.5
+    assert Fh.mha_proj_supported(H, D, C_, Tk)
+
+    def ref_attn(q, k, v):           # [B, C, T] each
+        qh, kh, vh = (t.reshape(B, H, D, -1) for t in (q, k, v))
+        att = torch.softmax(torch.einsum("bhdi,bhdj->bhij", qh, kh) * scale, dim=-1)
+        return torch.einsum("bhij,bhdj->bhdi", att, vh).reshape(B, C_, -1)
+
+    if form == "dit":
+        qkv = torch.randn(B, 3 * C_, Tk, generator=g)
+        x = torch.randn(B, C_, Tq, generator=g)
+        mask = (torch.rand(B, 1, Tq, generator=g) > 0.2).float()
+        gate = torch.randn(B, C_, generator=g)
+        o = ref_attn(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:])
+        ref = (torch.einsum("mc,bct->bmt", wt, o) + bias[None, :, None]) * mask * gate[:, :, None] + x
+        dq = qkv.to(device)
+        got = Fh.mha_proj(dq[:, :C_], dq[:, C_:2 * C_], dq[:, 2 * C_:], H, scale, wt.to(device), bias=bias.to(device),
+                          mask=mask.to(device), cscale=gate.to(device), res=x.to(device))
+        _close(got.cpu().numpy(), ref.numpy(), f"mha_proj dit B={B} T={Tk}")
+        return
+    # PLM layout: one [3C, Np] matrix, utterance b in columns b*T .. b*T + T - 1, rows padded to a multiple of 4 columns
+    T = Tk
+    Np = (B * T + 3) & ~3
+    qkv = torch.zeros(1, 3 * C_, Np)
+    qkv[0, :, :B * T] = torch.randn(3 * C_, B * T, generator=g)
+    x = torch.zeros(1, C_, Np)
+    x[0, :, :B * T] = torch.randn(C_, B * T, generator=g)
+    per = lambda m: m[:, :B * T].reshape(-1, B, T).permute(1, 0, 2)
+    q, k, v = (per(qkv[0, i * C_:(i + 1) * C_]) for i in range(3))
+    o = ref_attn(q.contiguous(), k.contiguous(), v.contiguous())
+    full = torch.einsum("mc,bct->bmt", wt, o) + bias[None, :, None] + per(x[0])
+    dqkv, dx = qkv.to(device), x.to(device)
+    dq, dk, dv = (per(dqkv[0, i * C_:(i + 1) * C_]) for i in range(3))
+    if form == "plm":
+        y = torch.zeros_like(dx)
+        Fh.mha_proj(dq, dk, dv, H, scale, wt.to(device), bias=bias.to(device), res=per(dx[0]), out=per(y[0]))
+        _close(per(y[0]).cpu().numpy(), full.numpy(), f"mha_proj plm B={B} T={T}")
+        assert float(y[0, :, B * T:].abs().max()) == 0.0 if Np > B * T else True      # padding columns untouched
+    else:
+        y = torch.empty(1, C_, B, device=device)
+        as_b = lambda m: m[0].permute(1, 0).unsqueeze(2)
+        res = dx[0][:, :B * T].reshape(-1, B, T)[:, :, T - 1].unsqueeze(0)           # [1, C, B], column stride T
+        Fh.mha_proj(dq[:, :, T - 1:], dk, dv, H, scale, wt.to(device), bias=bias.to(device), res=as_b(res), out=as_b(y))
+        _close(y[0].cpu().numpy(), full[:, :, T - 1].t().numpy(), f"mha_proj last B={B} T={T}")
+
+
 def test_long_prompts_have_no_attention_ceiling(device):
     """A 60-s prompt mel through the StyleEncoder (3 000 frames, ragged pair) and the denoiser's conformer block with
     3 200 frames on its attention axis (a 20-s prompt: denoiser/conformer.py:45-60 runs nn.MultiheadAttention along

@@ -163,6 +163,9 @@ def test_ctypes_structs_match_the_header(tmp_path):
     lines += [f'printf("%zu\\n", offsetof(hsp_conv1d_args, {f}));' for f in fields_c]
     lines += ['printf("%zu\\n", sizeof(hsp_mha_args));']
     lines += [f'printf("%zu\\n", offsetof(hsp_mha_args, {f}));' for f in fields_m]
+    fields_p = [f for f, _ in _lib.MhaProjArgs._fields_]
+    lines += ['printf("%zu\\n", sizeof(hsp_mha_proj_args));']
+    lines += [f'printf("%zu\\n", offsetof(hsp_mha_proj_args, {f}));' for f in fields_p]
     lines += ["return 0;}"]
     src.write_text("\n".join(lines))
     exe = tmp_path / "abi"
@@ -170,6 +173,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.Conv1dArgs)] + [getattr(_lib.Conv1dArgs, f).offset for f in fields_c]
     want += [ctypes.sizeof(_lib.MhaArgs)] + [getattr(_lib.MhaArgs, f).offset for f in fields_m]
+    want += [ctypes.sizeof(_lib.MhaProjArgs)] + [getattr(_lib.MhaProjArgs, f).offset for f in fields_p]
     assert vals == want
 
 
