@@ -331,6 +331,7 @@ def test_vocoder_wn_layers_and_dit_ffn_take_the_one_launch_path(monkeypatch):
     monkeypatch.setattr(M.Fh, "mask_mul", lambda x, m: x)
     monkeypatch.setattr(M.Fh, "layernorm_mod", lambda x, *a, **k: torch.empty_like(x))
     monkeypatch.setattr(M.Fh, "mha", lambda q, k, v, *a, **kw: torch.empty_like(q))
+    monkeypatch.setattr(M.Fh, "mha_proj_supported", lambda *a: False)   # the attention launches are not this test's subject
     monkeypatch.setattr(HL, "_launch", lambda kind, fn, a, fl, nb, soft=False, keep=(): (HL._DEFER.append((a, fl, nb, keep)) if HL._DEFER is not None else None) or 0)
     wn = M.WN(192, 5, 1, 3, gin_channels=0)
     blk = M.DiTConVBlock(192, 2, mlp_ratio=4.0, kernel=5)
