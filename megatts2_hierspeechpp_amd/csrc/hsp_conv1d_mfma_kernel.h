@@ -795,6 +795,73 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
     // constants (channel, phase, bias, row pointer) are resolved once per accumulator row; the
     // store loop has no loads, so nothing ever waits on vmcnt.  The `up` stores of one channel
     // (registers r&3 for up = 4, r&1 for up = 2) interleave into full lines in L2.
+    // (round 4) stride 4 / stride 2 with a whole number of channels per register group: the `up` phases of a channel
+    // sit in ADJACENT accumulator registers of one lane (rows r & 3 of a group of four) and land on `up` consecutive
+    // output samples, so they leave as ONE 16-B / 8-B store per lane -- lanes are consecutive t, a store instruction
+    // covers 512 / 256 contiguous bytes -- instead of `up` scalar stores at a 16-B / 8-B lane stride that only merge
+    // into full lines in L2 (4 x / 2 x the store instructions; the stride-2 launches of the Generator ran at 57 and 79
+    // TFLOP/s on them).  The first / last output group of a row (phases shifted outside [0, Lout) by the transposed
+    // conv's padding) takes scalar stores.
+    if ((a.up == 4 || a.up == 2) && !HSP_DBG(a, 262144)) {   // tuning bit 262144: the scalar phase stores of round 3
+      typedef float st4 __attribute__((ext_vector_type(4), aligned(4)));
+      typedef float st2 __attribute__((ext_vector_type(2), aligned(4)));
+      const float sc = a.scale * a.post_scale;
+      const int upl = a.up == 4 ? 2 : 1;               // log2(up)
+      static_for<TM>([&](auto ii) __attribute__((always_inline)) {
+        constexpr int i = decltype(ii)::value;
+        // register group q = r >> 2 holds rows mw + i * 32 + 8 q + 4 half + (0..3): one channel (up = 4) or two (up = 2)
+        float* yrow[4][2];
+        float bz[4][2];
+        bool rok[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int m = mw + i * 32 + 8 * q + 4 * half + 2 * c2;      // up = 2: channel c2 of the group; up = 4: c2 = 0 only
+            const int co = m >> upl;
+            rok[q][c2] = m < a.M && co < a.Cout;
+            yrow[q][c2] = a.y + (int64_t)b * a.y_bs + (int64_t)(rok[q][c2] ? co : 0) * a.y_cs;
+            bz[q][c2] = (rok[q][c2] && a.bias) ? a.bias[co] : 0.0f;
+          }
+        static_for<TN>([&](auto nn) __attribute__((always_inline)) {
+          constexpr int n = decltype(nn)::value;
+          const int t = tw + n * 32;
+          if (t < a.ncols) {
+            const int to0 = a.up * t - a.shuf_pad;
+            const bool inside = to0 >= 0 && to0 + a.up <= a.Lout;
+            static_for<4>([&](auto qq) __attribute__((always_inline)) {
+              constexpr int q = decltype(qq)::value;
+              if (a.up == 4) {
+                if (rok[q][0]) {
+                  const st4 v = {(acc[i][n][4 * q] + bz[q][0]) * sc, (acc[i][n][4 * q + 1] + bz[q][0]) * sc,
+                                 (acc[i][n][4 * q + 2] + bz[q][0]) * sc, (acc[i][n][4 * q + 3] + bz[q][0]) * sc};
+                  if (inside) *reinterpret_cast<st4*>(yrow[q][0] + to0) = v;
+                  else {
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph)
+                      if (to0 + ph >= 0 && to0 + ph < a.Lout) yrow[q][0][to0 + ph] = v[ph];
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                  if (rok[q][c2]) {
+                    const st2 v = {(acc[i][n][4 * q + 2 * c2] + bz[q][c2]) * sc, (acc[i][n][4 * q + 2 * c2 + 1] + bz[q][c2]) * sc};
+                    if (inside) *reinterpret_cast<st2*>(yrow[q][c2] + to0) = v;
+                    else {
+#pragma unroll
+                      for (int ph = 0; ph < 2; ++ph)
+                        if (to0 + ph >= 0 && to0 + ph < a.Lout) yrow[q][c2][to0 + ph] = v[ph];
+                    }
+                  }
+                }
+              }
+            });
+          }
+        });
+      });
+      return;
+    }
     const float up_inv = 1.0f / (float)a.up;
     static_for<TM>([&](auto ii) __attribute__((always_inline)) {
       constexpr int i = decltype(ii)::value;
