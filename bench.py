@@ -25,9 +25,9 @@ Printed JSON (one line, rank 0): metric/value per the driver contract plus
                    taken on this very build and launch mix, else null with the reason
   cpu_baseline  -- the CPU oracle (oracle/hsp_oracle.py) on this box's host cores: configs[0] (1 x 1 s) and a
                    bounded sample of configs[1] (8 x 4 s), N=1 only
-  extra_configs -- configs[0] on the GPU (1 x 1 s latency), configs[2] (full text->wav, batch 16) and configs[3]
-                   (vocoder + SpeechSR48, batch 32),
-                   N=1 only (tools/bench_extra.py)
+  extra_configs -- configs[0] on the GPU (1 x 1 s latency), configs[2] (full text->wav, batch 16), configs[3]
+                   (vocoder + SpeechSR48, batch 32) and the batch-1 latencies of the reference's own usage
+                   (vocoder 1 x 4 s, full TTS 1 x 4 s), N=1 only (tools/bench_extra.py)
 """
 import argparse
 import json
@@ -323,9 +323,9 @@ def vocoder_roofline(args, wl, result):
     # a run from inside) and committed under profiles/.  Quoted only when that profile was taken on THIS build of
     # the library, with this workload and this launch mix; otherwise null, with the reason.
     traffic, traffic_note, tj = None, None, None
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
     if not os.path.exists(path):
-        traffic_note = "no profiles/r03_traffic.json"
+        traffic_note = "no profiles/r04_traffic.json"
     else:
         with open(path) as fh:
             tj = json.load(fh)
@@ -346,6 +346,9 @@ def vocoder_roofline(args, wl, result):
                   % (len(tg), sum(m for _, _, m in tg)),
         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+        "traffic_source": "committed PMC profile profiles/r04_traffic.json (tools/pmc_traffic.sh; rocprofv3 cannot wrap a run "
+                          "from inside), quoted only when its kernel-source hash, workload and launch mix equal this run's -- "
+                          "not measured by this run",
         "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
         "launches_per_step": len(mf), "avg_launch_ms": tot_ms / max(len(mf), 1), "kernel_ms_per_step": tot_ms,
         "algorithmic_gflop_per_step": tot_fl / 1e9, "algorithmic_mb_per_step": tot_b / 1e6,
@@ -522,11 +525,21 @@ def main(argv=None):
             extra = {}
             _progress("extra_configs: vocoder 1 x 1 s")
             extra["vocoder_b1_1s"] = bench_extra.vocoder_b1_1s(wl.dev, steps=20, net=wl.model)
+            _progress("extra_configs: vocoder 1 x 4 s")
+            extra["vocoder_b1_4s"] = bench_extra.vocoder_b1(wl.dev, seconds=4.0, steps=20, net=wl.model)
             _progress("extra_configs: vocoder + SpeechSR48, batch 32")
             extra["sr48_b32"] = bench_extra.sr48_b32(wl.dev, steps=5, net=wl.model)
             del wl
             _progress("extra_configs: full TTS, batch 16")
-            extra["tts_b16"] = bench_extra.tts_b16(torch_device(), steps=3)
+            from megatts2_hierspeechpp_amd import inference_plm as IP, synth
+            import torch
+            models = IP.TtsModels(bench_extra.VOC_CFG, bench_extra.TTV_CFG)
+            models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0))
+                                    for k, v in models.state_dict().items()})
+            models.finalize(torch_device())
+            extra["tts_b16"] = bench_extra.tts_b16(torch_device(), steps=3, models=models)
+            _progress("extra_configs: full TTS, batch 1")
+            extra["tts_b1"] = bench_extra.tts_b1(torch_device(), steps=3, models=models)
             result["extra_configs"] = extra
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(result) + "\n").encode())

@@ -522,6 +522,18 @@ int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   auto waste_ok = [&](int bm) { return 4 * (int64_t)(((a.M + bm - 1) / bm) * bm - a.M) <= a.M; };
   const int64_t t64 = tiles(64, 64);
   if (t64 < 96) return -1;
-  if (t64 >= 850 && waste_ok(128) && a.ncols >= 512 && !a.split_row) return bg_go<2, 2>(a, s, plan_out);
+  // (round 4, tools/gemm_sweep.py over B in {1..64} x T in {50, 200, 1000}: profiles/r04_gemm_dispatch_table.txt)  The
+  // 128 x 128 shape runs one workgroup per CU, so what it costs is ROUNDS of 256 tiles: it wins only for many rows
+  // (M >= 768: the PLM's ff.0 / q-k-v) and when its last round is nearly full -- 4 000 columns of ff.0 are 288 tiles
+  // = two rounds for the work of 1.1 (60.5 against 44.9 us on 64 x 64), 3 200 columns are 225 tiles = one (32.4
+  // against 35.9).  Round 3's rule (from 850 small tiles upward) was up to 1.48 x off the better kernel.
+  // very large launches of a short K (the 192-channel 1x1s over >= 5 000 small tiles): the conv kernel's 128 x 128
+  // tiles at two per CU are ahead (WN res_skip at 64 x 1 000 frames: 95 against 117 us)
+  if (t64 >= 5000 && a.Cin <= 256 && !a.ln_c1 && !a.split_row && !bg_extended(a)) return -1;
+  if (t64 >= 700 && a.M >= 768 && waste_ok(128) && a.ncols >= 512 && !a.split_row) {
+    const int64_t t128 = tiles(128, 128);
+    const int64_t rounds = (t128 + 255) / 256;
+    if (100 * rounds * 256 <= 115 * t128) return bg_go<2, 2>(a, s, plan_out);
+  }
   return bg_go<1, 1>(a, s, plan_out);
 }

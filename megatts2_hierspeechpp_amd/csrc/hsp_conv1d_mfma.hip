@@ -61,7 +61,8 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     const int e = hsp_bgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
-  if ((short_seq || a.ln_c1 || a.split_row) && !HSP_DBG(a, 128)) {
+  // (tuning bit 1 << 24: try the latency-oriented token GEMMs whatever the launch size -- tools/gemm_sweep.py)
+  if ((short_seq || a.ln_c1 || a.split_row || HSP_DBG(a, 1 << 24)) && !HSP_DBG(a, 128)) {
     // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip), else the LDS-DMA
     // token GEMM (hsp_tokgemm.hip: second-output launches; tuning bit 131072 forces it for A/B runs)
     if (!HSP_DBG(a, 131072)) {

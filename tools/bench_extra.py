@@ -75,11 +75,11 @@ def conv_entry_profile(fn):
 
 def _pmc_traffic(workload, kind, launches):
     """HBM bytes per launch of `kind` from the committed PMC profile of this workload's dominant stage
-    (profiles/r03_traffic_extra.json, tools/pmc_traffic_extra.sh), or (None, reason)."""
+    (profiles/r04_traffic_extra.json, tools/pmc_traffic_extra.sh), or (None, reason)."""
     import json
-    path = os.path.join(ROOT, "profiles", "r03_traffic_extra.json")
+    path = os.path.join(ROOT, "profiles", "r04_traffic_extra.json")
     if workload is None or not os.path.exists(path):
-        return None, "no profiles/r03_traffic_extra.json"
+        return None, "no profiles/r04_traffic_extra.json"
     from megatts2_hierspeechpp_amd.build import source_id
     tj = json.load(open(path))
     if tj.get("kernel_source_sha16") != source_id():
@@ -234,7 +234,24 @@ def tts_b16(dev, steps=3, warmup=1, batch=16, phones=40, use_graph=True, models=
 
 
 # ----------------------------------------------------------------------------- configs[3]
-def vocoder_b1_1s(dev, steps=20, net=None):
+def vocoder_b1(dev, seconds=1.0, steps=20, net=None):
+    """Latency of ONE utterance through vocoder-only infer() -- batch 1 is the only way the reference itself runs
+    (inference_plm.py:277-287 loops over sentences one at a time) -- hipGraph replay, median of HIP-event pairs."""
+    out = vocoder_b1_1s(dev, steps=steps, net=net, frames=int(round(seconds * 50)))
+    out["metric"] = f"latency of vocoder-only infer(), 1 utterance x {seconds:g} s"
+    out["config"]["workload"] = f"vocoder infer() 1 x {seconds:g} s ({int(round(seconds * 50))} frames)"
+    return out
+
+
+def tts_b1(dev, steps=3, models=None):
+    """Latency of ONE sentence through the whole text -> wav chain (40 phones x 10 frames = 4 s), the reference's own
+    usage (inference_plm.py:277-287): tts_b16's flow at batch 1."""
+    out = tts_b16(dev, steps=steps, warmup=1, batch=1, models=models)
+    out["metric"] = "latency of full inference_plm.py text->wav, 1 utterance x 4 s"
+    return out
+
+
+def vocoder_b1_1s(dev, steps=20, net=None, frames=50):
     """BASELINE.json configs[0] (the reference's own CPU-runnable case: vocoder-only infer(), 1 utterance x 1 s) on
     the GPU: the latency of one small request, hipGraph replay.  bench.py's cpu_baseline times the same case on the
     host (config0_1x1s)."""
@@ -245,7 +262,7 @@ def vocoder_b1_1s(dev, steps=20, net=None):
         net.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0))
                              for k, v in net.state_dict().items()})
         net.finalize(dev)
-    B, T = 1, 50
+    B, T = 1, frames
     d = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_inputs(B, T, seed=2).items()}
 
     def step():
@@ -261,7 +278,7 @@ def vocoder_b1_1s(dev, steps=20, net=None):
     ms = event_median_ms(g.replay, steps)
     assert o.shape == (B, 1, 320 * T) and bool(torch.isfinite(o).all())
     return {"metric": "latency of vocoder-only infer(), 1 utterance x 1 s (BASELINE.json configs[0])",
-            "value": B * 320 * T / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms, "rtf": ms * 1e-3 / 1.0,
+            "value": B * 320 * T / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms, "rtf": ms * 1e-3 / (T / 50.0),
             "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
             "config": {"workload": "vocoder infer() 1 x 1 s (50 frames)", "launch_mode": "hipGraph replay, median of HIP-event pairs"}}
 
@@ -301,13 +318,17 @@ def sr48_b32(dev, steps=5, batch=32, net=None):
         g.replay()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    e[0].record()
-    o, _ = net.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
-    e[1].record()
-    sr(o)
-    e[2].record()
+    # stage split: each stage captured into its OWN hipGraph and replayed (device time; round 3 timed one eager pass
+    # with events, which measured host submission and first-size allocations: 157 + 296 ms inside a 101-ms step)
+    gv, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gv):
+        o, _ = net.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+    with torch.cuda.graph(gs):
+        sr(o)
+    for gg in (gv, gs):
+        gg.replay()
     torch.cuda.synchronize()
+    ms_v, ms_s = event_median_ms(gv.replay, max(steps, 3)), event_median_ms(gs.replay, max(steps, 3))
     assert o48.shape == (B, 1, 3 * 320 * T) and bool(torch.isfinite(o48).all())
     roof = dominant_roofline(conv_entry_profile(lambda: sr(o)), "sr48")
     if roof:
@@ -317,5 +338,6 @@ def sr48_b32(dev, steps=5, batch=32, net=None):
             "rtf": el / (B * 320 * T / 16000.0), "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
             "config": {"workload": f"vocoder infer() {B} x 4 s -> SpeechSR48 (x3 linear interp + AMP block, C=32)",
                        "launch_mode": "hipGraph replay of both stages"},
-            "stage_ms": {"vocoder_eager": e[0].elapsed_time(e[1]), "speechsr48_eager": e[1].elapsed_time(e[2])},
+            "stage_ms": {"vocoder": ms_v, "speechsr48": ms_s},
+            "stage_ms_note": "each stage replayed from its own hipGraph, median of HIP-event pairs",
             "roofline": roof}
