@@ -276,8 +276,8 @@ def vocoder_roofline(args, wl, result):
             plan = (C.c_int32 * 4)()
             L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
             tiles[len(rec)] = f"{plan[0]}x{plan[1]}"
-            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else ("hsp_conv1d_mfma_f32/tokgemm" if plan[2] == 0 else (
-                "hsp_conv1d_mfma_f32/rgemm" if plan[2] == -1 else "hsp_conv1d_mfma_f32/bgemm"))
+            kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else (
+                "hsp_conv1d_mfma_f32/rgemm" if plan[2] == -1 else "hsp_conv1d_mfma_f32/bgemm")
         rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
 
     Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
@@ -291,7 +291,7 @@ def vocoder_roofline(args, wl, result):
         hss.SERIAL_STREAMS = saved
     mf = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_conv1d_mfma_f32"]
     tg = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec
-          if kind in ("hsp_conv1d_mfma_f32/tokgemm", "hsp_conv1d_mfma_f32/rgemm", "hsp_conv1d_mfma_f32/bgemm")]
+          if kind in ("hsp_conv1d_mfma_f32/rgemm", "hsp_conv1d_mfma_f32/bgemm")]
     if args.dump_launches:
         agg = {}
         for kind, fl, nb, e0, e1, shp in rec:
@@ -342,7 +342,7 @@ def vocoder_roofline(args, wl, result):
                             + json.dumps(tj["conv1d_mfma_bytes_per_step"]))
     result["roofline"] = {
         "kernel": "conv1d_mfma_kernel (every tile shape the timed step launches; the 1x1 token-GEMM launches of the same "
-                  "entry point -- rgemm_kernel / tokgemm_kernel -- are excluded: %d launches, %.2f ms per step)"
+                  "entry point -- bgemm_kernel / rgemm_kernel -- are excluded: %d launches, %.2f ms per step)"
                   % (len(tg), sum(m for _, _, m in tg)),
         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
@@ -360,35 +360,16 @@ def vocoder_roofline(args, wl, result):
     audio_s = args.batch * args.seconds
     result["roofline"]["step_fma_fraction"] = 63.3e9 * audio_s / (result["ms_per_step"] * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     result["roofline"]["step_hbm_fraction"] = 391e6 * audio_s / (result["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
-    # continuity with BENCH_r02: the same figure over round 2's population -- its per-launch pass ran the front part as
-    # ONE batch group, where the WN layers / DiT FFNs take the fused two-GEMM kernel and only 167 launches reach
-    # conv1d_mfma_kernel (the Generator's and SourceNetwork's convs).  Not the timed step's mix: reported beside it.
-    rec2 = []
-
-    def hook2(kind, fl, nb, e0, e1, la):
-        if kind == "hsp_conv1d_mfma_f32":
-            plan = (C.c_int32 * 4)()
-            L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
-            if plan[2] > 0:
-                rec2.append((fl, e0, e1))
-
-    saved2 = (hss.SERIAL_STREAMS, hss.FRONT_SPLITS)
-    hss.SERIAL_STREAMS, hss.FRONT_SPLITS = True, 1
-    hip_layers.LAUNCH_HOOK = hook2
-    try:
-        wl.eager_step()
-        torch.cuda.synchronize()
-    finally:
-        hip_layers.LAUNCH_HOOK = None
-        hss.SERIAL_STREAMS, hss.FRONT_SPLITS = saved2
-    ms2 = sum(e0.elapsed_time(e1) for _, e0, e1 in rec2)
-    fl2 = sum(f for f, _, _ in rec2)
+    # continuity with BENCH_r02 / r03 (`round2_launch_mix`): the same figure over the launches with more than 200 output
+    # columns per utterance -- the Generator's and SourceNetwork's convs, round 2's 167-launch population (its per-launch
+    # pass ran the 50 Hz front part in a fused kernel that round 4 retired, so the population is selected by shape now)
+    long_ = [(fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, shp in rec if kind == "hsp_conv1d_mfma_f32" and shp[4] > 200]
+    ms2, fl2 = sum(m for _, m in long_), sum(f for f, _ in long_)
     result["roofline"]["round2_launch_mix"] = {
-        "launches_per_step": len(rec2), "kernel_ms_per_step": ms2, "achieved": fl2 / (ms2 * 1e-3) / 1e12,
+        "launches_per_step": len(long_), "kernel_ms_per_step": ms2, "achieved": fl2 / (ms2 * 1e-3) / 1e12,
         "frac": fl2 / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-        "note": "HSP_FRONT_SPLITS=1 pass (one front group: WN / FFN layers in gemm2_kernel), the population BENCH_r02's "
-                "roofline.frac was computed over (167 launches then; the 1x1 convs among them now run in bgemm_kernel); the "
-                "timed step does not run this mix"}
+        "note": "conv1d_mfma_kernel launches with more than 200 output columns per utterance (Generator + SourceNetwork): "
+                "the population BENCH_r02's roofline.frac was computed over; a subset of `roofline`'s launches"}
     if act_rec:
         # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
         a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)

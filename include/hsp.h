@@ -27,8 +27,6 @@
  *   - hsp_mha_f32: no sequence-length ceiling (score rows that do not fit LDS are walked in key blocks); head dim
  *     <= 128 without a relative-position window, <= 256 with one
  *   - hsp_lstm_bidir_f32: hidden size H <= 256 (one workgroup of 4 H <= 1024 threads holds the gate rows)
- *   - hsp_wn_layer_f32 / hsp_ffn_conv_f32: one launch for H = 192-class layers (hsp_fused_pair_supported says
- *     which), layer by layer behind the same entry point otherwise
  */
 #ifndef HSP_H_
 #define HSP_H_
@@ -451,14 +449,10 @@ int hsp_power_mel_log_f32(const float* spec, int64_t s_bs, int32_t s_ld, const f
  * hsp_wn_layer_f32: one layer of modules.WN (modules.py:156-175): `in_layer` (HSP_ROWS_GATE_WN: conv + g_l +
  *   tanh*sigmoid), then the residual half `res` (x = (x + rs[:H]) * mask) and the skip half `skip`
  *   (out += rs[H:]) of res_skip_layers; either of the two may be NULL (last layer: skip only).  `res` and `skip`
- *   read in_layer->y.  ONE launch (csrc/hsp_gemm2.hip: the gated activations of a 32-column tile stay in LDS and
- *   feed the res / skip GEMM; in_layer->y is then never written -- it is a workspace, not an output) when
- *   H % 192 == 0, res / skip are consecutive row ranges of one packed matrix with 192 or 384 rows in all, the
- *   tensors are 16-B addressable with T % 4 == 0, and res->y does not alias in_layer->x (the neighbouring tiles
- *   still read the old x as their halo); any other shape runs layer by layer with identical semantics.
+ *   read in_layer->y.  Issued layer by layer (round 2's one-launch kernel was retired in round 4: it lost to the
+ *   separate launches at every batch grouping of the step, profiles/r04_stage_split_policies.txt).
  * hsp_ffn_conv_f32: modules.FFN_Conv (modules.py:382-388) = `fc1` (conv k + bias + pointwise function) then `fc2`
- *   (1x1 conv reading fc1->y, with its mask / per-channel gate / residual epilogue).  ONE launch under the same
- *   conditions (fc1 rows a multiple of 384, fc2 rows 192 or 384), fc1->y again only a workspace.
+ *   (1x1 conv reading fc1->y, with its mask / per-channel gate / residual epilogue); two launches.
  * hsp_layernorm_modulate_f32: LayerNorm (no affine) + mask + modulate of the DiT blocks (modules.py:346-347,
  *   409-410) = hsp_layernorm_mod_f32 without gamma / beta. */
 int hsp_conv1d_f32(const hsp_conv1d_args* a, void* stream);
@@ -466,10 +460,6 @@ int hsp_convtr1d_f32(const hsp_conv1d_args* a, void* stream);
 int hsp_wn_layer_f32(const hsp_conv1d_args* in_layer, const hsp_conv1d_args* res, const hsp_conv1d_args* skip,
                      void* stream);
 int hsp_ffn_conv_f32(const hsp_conv1d_args* fc1, const hsp_conv1d_args* fc2, void* stream);
-/* 1 when hsp_wn_layer_f32(first, second, third) / hsp_ffn_conv_f32(first, second) would run as ONE launch, 0 when
- * it would run layer by layer (host-side check only: no launch, works without a GPU).  third may be NULL. */
-int hsp_fused_pair_supported(const hsp_conv1d_args* first, const hsp_conv1d_args* second,
-                             const hsp_conv1d_args* third);
 int hsp_layernorm_modulate_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, float eps,
                                const float* mask, const float* shift, const float* scale, int64_t mod_bs,
                                void* stream);

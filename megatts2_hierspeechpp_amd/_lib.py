@@ -136,7 +136,6 @@ SIGNATURES = {
     "hsp_convtr1d_f32": (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     "hsp_wn_layer_f32": (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs), _fp]),
     "hsp_ffn_conv_f32": (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs), _fp]),
-    "hsp_fused_pair_supported": (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs), C.POINTER(Conv1dArgs)]),
     "hsp_layernorm_modulate_f32": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp, _fp, _fp,
                                              C.c_int64, _fp]),
     "hsp_stft_frames_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -521,7 +521,7 @@ int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.ncols + bn - 1) / bn) * a.B; };
   auto waste_ok = [&](int bm) { return 4 * (int64_t)(((a.M + bm - 1) / bm) * bm - a.M) <= a.M; };
   const int64_t t64 = tiles(64, 64);
-  if (t64 < 96) return -1;
+  if (t64 < 96 && !a.split_row) return -1;   // (a second-output launch has no other kernel: better one launch here than two)
   // (round 4, tools/gemm_sweep.py over B in {1..64} x T in {50, 200, 1000}: profiles/r04_gemm_dispatch_table.txt)  The
   // 128 x 128 shape runs one workgroup per CU, so what it costs is ROUNDS of 256 tiles: it wins only for many rows
   // (M >= 768: the PLM's ff.0 / q-k-v) and when its last round is nearly full -- 4 000 columns of ff.0 are 288 tiles

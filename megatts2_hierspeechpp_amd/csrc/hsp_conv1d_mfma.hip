@@ -5,7 +5,6 @@
 // Reference call sites: see include/hsp.h (hsp_conv1d_args).
 #include "hsp_conv1d_mfma_kernel.h"
 
-int hsp_tokgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);  // hsp_tokgemm.hip; -1 = shape not taken
 int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);    // hsp_rgemm.hip; likewise
 int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out);    // hsp_bgemm.hip; likewise
 
@@ -61,15 +60,12 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     const int e = hsp_bgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
-  // (tuning bit 1 << 24: try the latency-oriented token GEMMs whatever the launch size -- tools/gemm_sweep.py)
+  // (tuning bit 1 << 24: try the register-path token GEMM whatever the launch size -- tools/gemm_sweep.py)
   if ((short_seq || a.ln_c1 || a.split_row || HSP_DBG(a, 1 << 24)) && !HSP_DBG(a, 128)) {
-    // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip), else the LDS-DMA
-    // token GEMM (hsp_tokgemm.hip: second-output launches; tuning bit 131072 forces it for A/B runs)
-    if (!HSP_DBG(a, 131072)) {
-      const int e = hsp_rgemm_try(a, s, plan_out);
-      if (e >= 0) return e;
-    }
-    const int e = hsp_tokgemm_try(a, s, plan_out);
+    // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip).  (The LDS-DMA token GEMM
+    // of rounds 1-3, hsp_tokgemm.hip, was retired in round 4: tools/gemm_sweep.py found no (shape, B, T) cell of
+    // profiles/r04_gemm_dispatch_table.txt where it beat the block GEMM or the register path by more than 2 %.)
+    const int e = hsp_rgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
   if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused input LayerNorm / second output: token-GEMM path only

@@ -18,18 +18,13 @@ from .hip_layers import Conv1d, HipLayer, Linear
 
 LRELU_SLOPE = 0.1  # modules.py:17
 
-# The one-launch WN layer / DiT FFN (csrc/hsp_gemm2.hip) is a serial chain of ~150 weight chunks per 32-column tile:
-# ~110 / ~200 us per launch however few tiles there are.  It pays when ONE launch has enough tiles to occupy the chip
-# (32 utterances x 200 frames in one group = 200 tiles: 85.0 ms per step against 87.2 with separate launches).  The
-# vocoder's front part runs as four batch groups on four streams by default, and there the separate, shorter launches
-# of the groups overlap better than four 50-tile fused launches (83.5 against 84.6 ms); a single short request
-# (1 x 50 frames = 2 tiles) spent 7.3 of its 13.7 ms in these two kernels and takes 9.2 ms without them.
-# 0 = always fuse where the library can.
-FUSE_MIN_TILES = int(os.environ.get("HSP_FUSE_MIN_TILES", "128"))
-
-
 def _fuse(x) -> bool:
-    return x.shape[0] * ((x.shape[2] + 31) // 32) >= FUSE_MIN_TILES
+    """Route a WN layer / DiT FFN through the entry points SURVEY.md 8(b) names for them (hsp_wn_layer_f32,
+    hsp_ffn_conv_f32) -- only under HSP_SURVEY_ABI: they issue the same launches the default path issues itself.
+    (Rounds 2-3 had a one-launch kernel behind them, csrc/hsp_gemm2.hip, chosen by a tile-count policy; it lost to the
+    separate launches at every batch grouping of the step and was retired in round 4:
+    profiles/r04_stage_split_policies.txt.)"""
+    return hip_layers.SURVEY_ABI
 
 
 class LayerNorm(HipLayer):
@@ -58,11 +53,9 @@ class LayerNorm(HipLayer):
 
 
 class WN(nn.Module):
-    """modules.WN (modules.py:111-176).  Per layer either ONE launch (hsp_wn_layer_f32 -> csrc/hsp_gemm2.hip: gated
-    conv, tanh * sigmoid and the res / skip 1x1 with the activations on chip) when the launch has at least
-    FUSE_MIN_TILES column tiles, or two: the gated in-conv (conv k + conditioning bias + tanh * sigmoid in the
-    epilogue) and one token-GEMM launch writing both row halves of res_skip (residual update of x, accumulation of
-    the skip output; hsp_conv1d_args.split_row)."""
+    """modules.WN (modules.py:111-176).  Two launches per layer: the gated in-conv (conv k + conditioning bias +
+    tanh * sigmoid in the epilogue) and one token-GEMM launch writing both row halves of res_skip (residual update of
+    x, accumulation of the skip output; hsp_conv1d_args.split_row)."""
 
     def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
         super().__init__()
@@ -86,10 +79,7 @@ class WN(nn.Module):
             self.res_skip_layers.append(Conv1d(hidden_channels, rs, 1, weight_norm=True))
 
     def forward(self, x, x_mask, g=None, **kwargs):
-        """One hsp_wn_layer_f32 call per layer when the launch has enough column tiles (FUSE_MIN_TILES).  The library
-        runs it as ONE launch where it can (csrc/hsp_gemm2.hip: H = 192, the 50 Hz tensors of the vocoder) and layer by
-        layer otherwise; either way the activations tensor `acts` is only a workspace.  x is never updated in place: the fused kernel's neighbouring column tiles read
-        the old x as their halo."""
+        """`acts` (the gated activations) is a workspace between a layer's two launches.  x is never updated in place."""
         H = self.hidden_channels
         gc = self.cond_layer(g) if g is not None else None  # [B, 2H*n, 1]
         out = None
@@ -198,8 +188,7 @@ class DiTConVBlock(nn.Module):
             o = Fh.mha(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale)
             x = self.attn.proj(o, mask=x_mask, mask_mode=L.MASK_PRE, cscale=g_a, res=x)
         h = Fh.layernorm_mod(x, 1e-6, shift=sh_m, scale=sc_m)
-        # fc1 -> GELU -> fc2 as ONE hsp_ffn_conv_f32 call (one launch where the library has the fused kernel);
-        # fc2(y * mask) * mask == (W y + b) * mask for a 1x1 conv and a 0/1 mask
+        # fc1 -> GELU -> fc2; fc2(y * mask) * mask == (W y + b) * mask for a 1x1 conv and a 0/1 mask
         fuse = _fuse(x)
         with (hip_layers.deferred() if fuse else contextlib.nullcontext()) as args:
             y = self.mlp.fc1(h, act=L.ACT_GELU_TANH)

@@ -31,24 +31,24 @@ def test_golden(name, device):
         _close(o, r, f"{name}[{i}]")
 
 
-@pytest.mark.parametrize("name", ["wn_h192", "dit_block", "coupling", "flow", "posterior_sf", "infer_config1", "infer_ragged",
-                                  "vc_noise_control", "vc_plain"])
-def test_golden_through_the_fused_two_gemm_kernel(name, device, monkeypatch):
-    """The golden cases are a few tiles wide, below the tile count at which the host mirror chooses the one-launch WN
-    layer / DiT FFN (modules.FUSE_MIN_TILES): here every such layer is forced through csrc/hsp_gemm2.hip and must meet
-    the same reference outputs; the separate-launch path is what test_golden runs."""
-    from megatts2_hierspeechpp_amd import hip_layers, modules
+@pytest.mark.parametrize("name", ["wn_h192", "dit_block", "flow", "posterior_sf", "infer_ragged"])
+def test_golden_through_the_layer_entry_points(name, device, monkeypatch):
+    """hsp_wn_layer_f32 / hsp_ffn_conv_f32 -- the names SURVEY.md 8(b) gives a WN layer and the DiT FFN -- issue the
+    layer's launches themselves (the in-conv, then res and skip as row ranges: not the one split-row launch of the default
+    path); the golden cases through them meet the same reference outputs.  (Rounds 2-3 tested a one-launch kernel here;
+    it was retired in round 4)"""
+    from megatts2_hierspeechpp_amd import hip_layers
     if name not in H.fixture_names():
         pytest.skip(f"no fixture {name}")
     calls = []
     orig = hip_layers.launch_group
-    monkeypatch.setattr(modules, "FUSE_MIN_TILES", 0)
+    monkeypatch.setattr(hip_layers, "SURVEY_ABI", True)
     monkeypatch.setattr(hip_layers, "launch_group", lambda kind, *a, **k: (calls.append(kind), orig(kind, *a, **k))[1])
     meta, arrays = H.load_fixture(name)
     outs = H.run_hip(meta, arrays, device)
-    assert calls, "no fused launch was issued"
+    assert "hsp_wn_layer_f32" in calls or "hsp_ffn_conv_f32" in calls, "no layer entry point was called"
     for i, (o, r) in enumerate(zip(outs, H.outputs(arrays))):
-        _close(o, r, f"{name}[{i}] (fused)")
+        _close(o, r, f"{name}[{i}] (layer entry points)")
 
 
 @pytest.mark.parametrize("name", ["infer_config1", "vc_noise_control", "tts_e2e", "plm_t12", "speechsr48", "speechsr24_real", "speechsr48_real",
@@ -125,7 +125,13 @@ def test_survey_abi_names_give_identical_results(name, device):
         hip_layers.SURVEY_ABI = old
     for o, b_, r in zip(outs, base, H.outputs(arrays)):
         _close(o, r, name)
-        assert np.array_equal(o, b_), f"{name}: SURVEY-named entry points changed the result"
+        # bit-identical where the named entry points issue the very launches of the default path; a WN layer behind
+        # hsp_wn_layer_f32 runs res and skip as two row-range launches instead of one split-row launch (same
+        # arithmetic per output, another kernel's summation order)
+        if name in ("convtr_k11_s5", "generator"):
+            assert np.array_equal(o, b_), f"{name}: SURVEY-named entry points changed the result"
+        else:
+            assert float(np.abs(o - b_).max()) <= 2e-5 * max(1.0, float(np.abs(b_).max())), name
 
 
 # ------------------------------------------------------------ (b) oracle, other sizes
@@ -331,7 +337,7 @@ def test_activation_post_conv_post_tanh_vs_oracle(C_, K, L, B, device):
 
 def test_wn_with_dilation_rate_2_vs_oracle(device):
     """modules.WN(dilation_rate = 2, 5 layers): dilations 1 ... 16, the last in-layer's halo (67 columns) takes the
-    wide-pitch gated tile shape; both launch policies (layer by layer / the fused entry point's own fallback)."""
+    wide-pitch gated tile shape; through the default launches and through the hsp_wn_layer_f32 entry point."""
     from oracle import hsp_oracle as O
     from megatts2_hierspeechpp_amd import functional as Fh
     from megatts2_hierspeechpp_amd import modules
@@ -349,13 +355,14 @@ def test_wn_with_dilation_rate_2_vs_oracle(device):
     g = torch.from_numpy(rng.standard_normal((2, 256, 1)).astype(np.float32))
     ref = O.wavenet({"w." + k: v for k, v in sd.items()}, "w", x, mask_c, g, 192, 5, 5, dilation_rate=2).numpy()
     mask = Fh.sequence_mask(torch.from_numpy(lens).to(device), T)
-    for fuse_min in (1 << 30, 0):
-        modules.FUSE_MIN_TILES, saved = fuse_min, modules.FUSE_MIN_TILES
+    from megatts2_hierspeechpp_amd import hip_layers
+    for named in (False, True):            # the default launches / the hsp_wn_layer_f32 entry point
+        hip_layers.SURVEY_ABI, saved = named, hip_layers.SURVEY_ABI
         try:
             got = wn(x.to(device), mask, g=g.to(device)).cpu().numpy()
         finally:
-            modules.FUSE_MIN_TILES = saved
-        _close(got, ref, f"WN dilation_rate 2 (FUSE_MIN_TILES {fuse_min})")
+            hip_layers.SURVEY_ABI = saved
+        _close(got, ref, f"WN dilation_rate 2 (SURVEY_ABI {named})")
 
 
 def test_linear_interp_long_sequence_matches_torch_cpu(device):
@@ -1238,7 +1245,7 @@ def test_second_output_gemm_matches_two_launches(device):
     from megatts2_hierspeechpp_amd import _lib as L
     from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
     g = torch.Generator().manual_seed(3)
-    for H_, B, T in [(192, 3, 200), (64, 2, 52), (512, 1, 120)]:
+    for H_, B, T in [(192, 3, 200), (192, 1, 52), (512, 1, 120), (192, 8, 200)]:
         lay = Conv1d(H_, 2 * H_, 1, weight_norm=True)
         with torch.no_grad():
             for p_ in lay.parameters():
@@ -1254,18 +1261,22 @@ def test_second_output_gemm_matches_two_launches(device):
         out_new = lay(acts, row_range=(H_, 2 * H_))
         both = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, prev.clone(), True))
         assert both is not None, (H_, B, T)
-        # the two single-output launches take the register-path GEMM, the second-output launch the LDS-DMA token GEMM:
+        # the two single-output launches take the register-path GEMM, the second-output launch the block token GEMM:
         # same products, another summation order (K split across waves) -> equal to fp32 rounding, not bit for bit
         _close(both[0].cpu().numpy(), x_ref.cpu().numpy(), "split: first output")
         _close(both[1].cpu().numpy(), out_ref.cpu().numpy(), "split: accumulated second output")
         first = lay(acts, res=x, mask=mask, mask_mode=L.MASK_POST, split_out=(H_, None, False))
         _close(first[0].cpu().numpy(), x_ref.cpu().numpy(), "split: first output (fresh second)")
         _close(first[1].cpu().numpy(), out_new.cpu().numpy(), "split: fresh second output")
-    # no fused kernel: split row off the 64-row tile grid, or a column count the token GEMM does not take
+    # no fused kernel: split row off the 64-row tile grid, fewer than 96 input channels, or a column count the block
+    # token GEMM does not take (the host mirror then issues the two launches: modules.WN.forward)
     lay = Conv1d(96, 192, 1, weight_norm=True)
     finalize(lay, device)
     a96 = torch.randn(2, 96, 40, generator=g).to(device)
     assert lay(a96, split_out=(96, None, False)) is None
+    lay = Conv1d(64, 128, 1, weight_norm=True)
+    finalize(lay, device)
+    assert lay(torch.randn(2, 64, 52, generator=g).to(device), split_out=(64, None, False)) is None
     lay = Conv1d(64, 128, 1, weight_norm=True)
     finalize(lay, device)
     assert lay(torch.randn(2, 64, 37, generator=g).to(device), split_out=(64, None, False)) is None

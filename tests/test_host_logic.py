@@ -306,59 +306,36 @@ def test_release_library_refuses_the_tuning_word():
     assert "HSP_CONV_DEBUG" not in open(os.path.join(os.path.dirname(L_.__file__), "hip_layers.py")).read()
 
 
-def test_vocoder_wn_layers_and_dit_ffn_take_the_one_launch_path(monkeypatch):
-    """hsp_wn_layer_f32 / hsp_ffn_conv_f32 run as ONE launch (csrc/hsp_gemm2.hip) for the shapes of the vocoder path:
-    WN H = 192 and the DiT FFN 192 -> 768 -> 192, at 4-s batches, 1-s single utterances and ragged lengths.  Checked
-    through the library's own host-side predicate with the argument structs the host mirror really builds (device
-    pointers replaced by host addresses: nothing is launched)."""
+def test_wn_layers_and_dit_ffn_reach_their_named_entry_points_only_under_survey_abi(monkeypatch):
+    """modules.WN / DiTConVBlock issue their own launches by default; under HSP_SURVEY_ABI a WN layer goes through
+    hsp_wn_layer_f32 (in-layer, res, skip: three structs, the last layer two) and the DiT FFN through hsp_ffn_conv_f32
+    (SURVEY.md 8(b) names).  Host logic only: device pointers replaced by host addresses, nothing is launched."""
     from megatts2_hierspeechpp_amd import _lib as L_, hip_layers as HL, modules as M
-    lib = L_.lib()
     monkeypatch.setattr(L_, "ptr", lambda t: None if t is None else t.data_ptr())
     monkeypatch.setattr(L_, "fptr", lambda t: None if t is None else t.data_ptr())
     monkeypatch.setattr(HL, "_zeros", lambda dev: torch.zeros(64))
-    seen = []
-
-    def fake_group(kind, fn, structs, *extra):
-        ptrs = [ctypes.byref(e[0]) if e is not None else None for e in structs]
-        if kind == "hsp_wn_layer_f32":
-            first, second, third = (ptrs[0], ptrs[1], ptrs[2]) if ptrs[1] is not None else (ptrs[0], ptrs[2], None)
-        else:
-            first, second, third = ptrs[0], ptrs[1], None
-        seen.append((kind, lib.hsp_fused_pair_supported(first, second, third)))
-
-    monkeypatch.setattr(HL, "launch_group", fake_group)
-    monkeypatch.setattr(M, "FUSE_MIN_TILES", 0)          # the tile-count policy is tested below
+    seen, plain = [], []
+    monkeypatch.setattr(HL, "launch_group", lambda kind, fn, structs, *extra: seen.append((kind, [e is not None for e in structs])))
     monkeypatch.setattr(M.Fh, "mask_mul", lambda x, m: x)
     monkeypatch.setattr(M.Fh, "layernorm_mod", lambda x, *a, **k: torch.empty_like(x))
     monkeypatch.setattr(M.Fh, "mha", lambda q, k, v, *a, **kw: torch.empty_like(q))
     monkeypatch.setattr(M.Fh, "mha_proj_supported", lambda *a: False)   # the attention launches are not this test's subject
-    monkeypatch.setattr(HL, "_launch", lambda kind, fn, a, fl, nb, soft=False, keep=(): (HL._DEFER.append((a, fl, nb, keep)) if HL._DEFER is not None else None) or 0)
+    monkeypatch.setattr(HL, "_launch", lambda kind, fn, a, fl, nb, soft=False, keep=(): (
+        HL._DEFER.append((a, fl, nb, keep)) if HL._DEFER is not None else plain.append(kind)) and 0 or 0)
     wn = M.WN(192, 5, 1, 3, gin_channels=0)
     blk = M.DiTConVBlock(192, 2, mlp_ratio=4.0, kernel=5)
     for m in list(wn.modules()) + list(blk.modules()):
         if isinstance(m, HL.Conv1d):
             m._w = torch.zeros(m.k * m.cin * m.M)
             m._b = torch.zeros(m.cout)
-    for B, T in ((32, 200), (1, 50), (3, 333), (2, 36)):
-        seen.clear()
-        x, mask = torch.zeros(B, 192, T), torch.ones(B, 1, T)
-        wn(x, mask)
-        blk(x, None, mask, mod=torch.zeros(B, 6 * 192, 1), premasked=True)
-        assert [k for k, _ in seen] == ["hsp_wn_layer_f32"] * 3 + ["hsp_ffn_conv_f32"], seen
-        assert all(ok == 1 for _, ok in seen), (B, T, seen)
-    # a WN whose width the fused kernel does not cover runs layer by layer (W2VDecoder: H = 512)
-    seen.clear()
-    wn512 = M.WN(512, 5, 1, 2, gin_channels=0)
-    for m in wn512.modules():
-        if isinstance(m, HL.Conv1d):
-            m._w, m._b = torch.zeros(m.k * m.cin * m.M), torch.zeros(m.cout)
-    wn512(torch.zeros(2, 512, 200), torch.ones(2, 1, 200))
-    assert [ok for _, ok in seen] == [0, 0]
-    # policy of the host mirror: a launch with fewer than FUSE_MIN_TILES 32-column tiles issues the separate launches
-    # (a fused launch is a ~200 us serial chain per tile however few tiles there are)
-    monkeypatch.setattr(M, "FUSE_MIN_TILES", 32)
-    assert M._fuse(torch.zeros(32, 192, 200)) and M._fuse(torch.zeros(8, 192, 200)) and M._fuse(torch.zeros(1, 192, 1024))
-    assert not M._fuse(torch.zeros(1, 192, 50)) and not M._fuse(torch.zeros(4, 192, 200))
-    seen.clear()
-    wn(torch.zeros(1, 192, 50), torch.ones(1, 1, 50))
-    assert seen == []
+    x, mask = torch.zeros(2, 192, 36), torch.ones(2, 1, 36)
+    monkeypatch.setattr(HL, "SURVEY_ABI", False)
+    wn(x, mask)
+    blk(x, None, mask, mod=torch.zeros(2, 6 * 192, 1), premasked=True)
+    assert seen == [] and len(plain) >= 3 * 2 + 2           # no grouped call: every layer launches itself
+    monkeypatch.setattr(HL, "SURVEY_ABI", True)
+    plain.clear()
+    wn(x, mask)
+    blk(x, None, mask, mod=torch.zeros(2, 6 * 192, 1), premasked=True)
+    assert [k for k, _ in seen] == ["hsp_wn_layer_f32"] * 3 + ["hsp_ffn_conv_f32"], seen
+    assert seen[0][1] == [True, True, True] and seen[2][1] == [True, False, True]   # last WN layer: skip only

@@ -54,7 +54,7 @@ def conv_entry_profile(fn):
         if kind == "hsp_conv1d_mfma_f32":
             plan = (C.c_int32 * 4)()
             L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
-            kind = "conv1d_mfma_kernel" if plan[2] > 0 else ("tokgemm_kernel" if plan[2] == 0 else ("rgemm_kernel" if plan[2] == -1 else "bgemm_kernel"))
+            kind = "conv1d_mfma_kernel" if plan[2] > 0 else ("rgemm_kernel" if plan[2] == -1 else "bgemm_kernel")
         rec.append((kind, fl, nb, e0, e1))
 
     saved = hss.SERIAL_STREAMS
