@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r03_traffic.json.
+"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r04_traffic.json.
 bench.py quotes `roofline.traffic` from that file ONLY when the kernel-source hash, the workload size and the launch mix
 recorded here equal the run's own (the library is identified by the hash of its kernel sources).
 
-    python tools/pmc_summarize.py gpurun_out profiles/r03_traffic.json
+    python tools/pmc_summarize.py gpurun_out profiles/r04_traffic.json
 
 FETCH_SIZE on gfx950 under-reports wide coalesced reads (exactly 1/2 for 16-B-per-lane streams, MI355X_MICROARCH.md);
 three figures are given for every kernel class: raw (as counted), x2 (the guide's literal correction) and calibrated
@@ -17,7 +17,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = ["conv1d_mfma_kernel", "gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "bgemm_kernel", "act1d_seg_kernel", "act1d_kernel",
+CLASSES = ["conv1d_mfma_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "act1d_seg_kernel", "act1d_kernel",
            "mha_mfma_kernel", "mha_tok_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel"]
 B, T = 32, 200
 STEPS = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
@@ -74,7 +74,7 @@ res = {
     "conv1d_mfma_bytes_per_step": three(conv),
     "act1d_seg_bytes_per_step": three(act),
 }
-for name in ("gemm2_kernel", "tokgemm_kernel", "rgemm_kernel", "bgemm_kernel"):
+for name in ("rgemm_kernel", "bgemm_kernel", "mha_proj_kernel"):
     if name in out:
         res[name + "_bytes_per_step"] = three(out[name])
 json.dump(res, open(dst, "w"), indent=1)
