@@ -168,6 +168,11 @@ typedef struct hsp_conv1d_args {
    * layer input, to a [D, B] output without a gather launch in between (ttv_v1/transformer_mega.py:118-131 on the
    * last position only); any other kernel / shape refuses res_ts > 1 with HSP_EINVAL. */
   int64_t res_ts;
+  /* Weight stride between the B "utterances" of the batch (elements; 0 = one weight matrix for all of them, as every
+   * layer of the reference has).  Non-zero only for the frequency-domain form of a long dilated conv (round 4,
+   * hsp_dftseg_*_f32 below), where the batch index is the frequency BIN and every bin has its own [Cin][M] matrix.
+   * The implicit-GEMM conv kernel only (the token GEMMs refuse it). */
+  int64_t w_bs;
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Behind this entry point: the
@@ -438,6 +443,38 @@ int hsp_stft_frames_f32(const float* x, const float* window, float* frames, int3
 int hsp_power_mel_log_f32(const float* spec, int64_t s_bs, int32_t s_ld, const float* fb, const int32_t* f_lo,
                           const int32_t* f_hi, float* out, int32_t B, int32_t n_freqs, int32_t n_mels,
                           int32_t T_out, float eps, void* stream);
+
+/* ------------------------------------------------ frequency-domain form of a long dilated Conv1d (round 4)
+ * The same-length, stride-1 Conv1d(C -> C, k taps, dilation d, zero padding `pad`) of an AMP block
+ * (hierspeechpp_speechsynthesizer.py:340-392) as overlap-save with a 128-point real DFT (csrc/hsp_dftseg.hip):
+ *   hsp_dftseg_fwd_f32   x [B][C][L] -> xf [64 bins][2 C][Np]: row part * C + c of bin j holds Re (part 0) / Im (part 1)
+ *                        of bin j of channel c (bin 0: DC in part 0, Nyquist in part 1); column n = (b * d + p) * nseg + s
+ *                        is segment s of phase p (the samples xpad[p + d i]) of utterance b;
+ *                        nseg = ceil(ceil(L / d) / (129 - k)), Np >= B d nseg (a multiple of 4)
+ *   hsp_conv1d_mfma_f32  one launch: B = 64 (the bins), Cin = M = 2 C, K = 1, Lin = Np, w_bs = 4 C^2 -- per bin the real
+ *                        block matrix [[Wr, Wi], [-Wi, Wr]] of conj(rfft(w, 128)) (bin 0: [[W_dc, 0], [0, W_nyquist]])
+ *   hsp_dftseg_inv_f32   yf [64][2 C][Np] -> y [B][C][L] = ((corr + bias[c] + res) [+ y]) * post_scale
+ * `dft` = the 128 x 128 transform matrix, row-major: forward F[row][tap] (rows 0..63 cos(2 pi r i / 128), row 64
+ * (-1)^i, rows 65..127 -sin(2 pi (r - 64) i / 128)); inverse Finv[time][row] ((1 | 2) / 128 times the same).  fp32
+ * arithmetic on the fp32 MFMA; against float64 as close as the direct fp32 sum (tools/fft_conv_err.py). */
+typedef struct hsp_dftseg_args {
+  const float* x;   /* forward: input [B][C][L], unit time stride */
+  int64_t x_bs, x_cs;
+  float* y;         /* inverse: output */
+  int64_t y_bs, y_cs;
+  int32_t B, C, L;
+  int32_t k, dil, pad, nseg, Np;
+  float* xf;        /* forward: written; inverse: read */
+  int64_t xf_bs;    /* plane (bin) stride >= 2 C Np */
+  const float* dft;
+  const float* bias; /* inverse epilogue: optional */
+  const float* res;
+  int64_t res_bs, res_cs;
+  int32_t accumulate;
+  float post_scale;
+} hsp_dftseg_args;
+int hsp_dftseg_fwd_f32(const hsp_dftseg_args* a, void* stream);
+int hsp_dftseg_inv_f32(const hsp_dftseg_args* a, void* stream);
 
 /* ------------------------------------------------ SURVEY.md §8(b) names (dispatching entry points) */
 /* The minimum export set of SURVEY.md §8(b) under its own names; each forwards to the entry points above.

@@ -44,7 +44,7 @@ class Conv1dArgs(C.Structure):
         ("accumulate", C.c_int32), ("post_scale", C.c_float), ("debug", C.c_int32),
         ("ln_c1", _fp), ("ln_eps", C.c_float),
         ("split_row", C.c_int32), ("accumulate2", C.c_int32), ("mask_mode2", C.c_int32), ("y2", _fp),
-        ("y2_bs", C.c_int64), ("y2_cs", C.c_int64), ("res_ts", C.c_int64),
+        ("y2_bs", C.c_int64), ("y2_cs", C.c_int64), ("res_ts", C.c_int64), ("w_bs", C.c_int64),
     ]
 
 
@@ -76,6 +76,19 @@ class MhaProjArgs(C.Structure):
     ]
 
 
+class DftSegArgs(C.Structure):
+    """Mirror of ``hsp_dftseg_args``."""
+    _fields_ = [
+        ("x", _fp), ("x_bs", C.c_int64), ("x_cs", C.c_int64),
+        ("y", _fp), ("y_bs", C.c_int64), ("y_cs", C.c_int64),
+        ("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32),
+        ("k", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32), ("nseg", C.c_int32), ("Np", C.c_int32),
+        ("xf", _fp), ("xf_bs", C.c_int64), ("dft", _fp),
+        ("bias", _fp), ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64),
+        ("accumulate", C.c_int32), ("post_scale", C.c_float),
+    ]
+
+
 # symbol -> (restype, argtypes); every symbol include/hsp.h declares
 SIGNATURES = {
     "hsp_version": (C.c_int, []),
@@ -94,6 +107,8 @@ SIGNATURES = {
                                         C.c_int64, _fp, _fp, _fp]),
     "hsp_mha_f32": (C.c_int, [C.POINTER(MhaArgs), _fp]),
     "hsp_mha_proj_f32": (C.c_int, [C.POINTER(MhaProjArgs), _fp]),
+    "hsp_dftseg_fwd_f32": (C.c_int, [C.POINTER(DftSegArgs), _fp]),
+    "hsp_dftseg_inv_f32": (C.c_int, [C.POINTER(DftSegArgs), _fp]),
     "hsp_mha_proj_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hsp_masked_mean_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_mask_mul_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),

@@ -7,7 +7,7 @@ namespace {
 // shapes the MFMA kernels do not take (stride, degenerate channel / length counts, SiLU prologue) go to the VALU kernel
 bool wants_direct(const hsp_conv1d_args& a) {
   const bool gated = a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU;
-  return !gated && a.rows == HSP_ROWS_PLAIN && a.prologue != HSP_PRO_ACT1D && !a.ln_c1 &&
+  return !gated && a.rows == HSP_ROWS_PLAIN && a.prologue != HSP_PRO_ACT1D && !a.ln_c1 && !a.w_bs &&
          (a.stride != 1 || a.Cin < 8 || a.Cout < 8 || a.Lout < 8 || a.prologue == HSP_PRO_SILU);
 }
 }  // namespace

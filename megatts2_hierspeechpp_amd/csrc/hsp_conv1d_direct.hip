@@ -233,6 +233,7 @@ extern "C" int hsp_conv1d_direct_f32(const hsp_conv1d_args* ap, void* stream) {
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_SILU) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
   if (a.res && a.res_ts > 1) return HSP_EINVAL;   // strided residual: register-path token GEMM only
+  if (a.w_bs) return HSP_EINVAL;                  // per-batch weights (frequency bins): the implicit-GEMM kernel only
   if (a.ln_c1 || a.split_row) return HSP_EINVAL;  // fused LayerNorm / second output: token-GEMM path only
   if (linear_vec_fast(a)) {
     const unsigned gx = (unsigned)((a.Cout + 63) / 64), gy = (unsigned)((a.B + LV_BB - 1) / LV_BB);

@@ -19,7 +19,8 @@ int validate(const hsp_conv1d_args& a) {
   if (a.B <= 0 || a.Cin <= 0 || a.Lin <= 0 || a.K <= 0 || a.M <= 0 || a.Cout <= 0 || a.Lout <= 0 || a.ncols <= 0)
     return HSP_EINVAL;
   if (a.stride != 1 || (a.M & 3) || (a.w_ld & 3) || a.w_ld < a.M || a.dil < 1) return HSP_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(a.w) & 15) != 0) return HSP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a.w) & 15) != 0 || a.w_bs < 0 || (a.w_bs & 3)) return HSP_EINVAL;
+  if (a.w_bs && (a.ln_c1 || a.split_row || (a.res && a.res_ts > 1))) return HSP_EINVAL;   // per-batch weights: conv tiles only
   // the kernel indexes one utterance / the weight matrix with 32-bit element offsets
   if ((int64_t)a.K * a.Cin * a.w_ld >= (1ll << 31)) return HSP_EINVAL;
   if ((int64_t)a.Cin * a.x_cs + (int64_t)a.Lin * a.x_ts >= (1ll << 31) || a.x_cs < 0 || a.x_ts < 0) return HSP_EINVAL;
@@ -56,12 +57,12 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   }
   // 1x1 GEMMs with enough outputs for about one 128 x 128 / 128 x 64 tile per CU (the PLM loop beyond ~60 prefix
   // positions): the throughput-oriented token GEMM (hsp_bgemm.hip)
-  if (a.K == 1 && !HSP_DBG(a, 128)) {
+  if (a.K == 1 && !a.w_bs && !HSP_DBG(a, 128)) {
     const int e = hsp_bgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
   // (tuning bit 1 << 24: try the register-path token GEMM whatever the launch size -- tools/gemm_sweep.py)
-  if ((short_seq || a.ln_c1 || a.split_row || HSP_DBG(a, 1 << 24)) && !HSP_DBG(a, 128)) {
+  if ((short_seq || a.ln_c1 || a.split_row || HSP_DBG(a, 1 << 24)) && !a.w_bs && !HSP_DBG(a, 128)) {
     // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip).  (The LDS-DMA token GEMM
     // of rounds 1-3, hsp_tokgemm.hip, was retired in round 4: tools/gemm_sweep.py found no (shape, B, T) cell of
     // profiles/r04_gemm_dispatch_table.txt where it beat the block GEMM or the register path by more than 2 %.)

@@ -989,7 +989,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
   if (wave >= C::NCW) {
     // ------------------------------------------------------------ producers
     const int pw = wave - C::NCW;
-    const ProdArgs pa{a.w, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
+    const float* const wb = a.w + (int64_t)b * a.w_bs;   // per-"utterance" weights (frequency bins, hsp.h: w_bs), else w_bs == 0
+    const ProdArgs pa{wb, a.zeros, a.alpha_exp, a.beta_inv, a.filt, a.K, a.Cin, a.Lin, a.M, a.w_ld, (int)a.x_cs,
                       (int)a.x_ts, a.prologue, a.slope};
     const float* xb = a.x + (int64_t)b * a.x_bs;
     using PR = Prod<C>;
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       const int p0a = p0 & ~3;
       const bool fast = xvec && m0 + BM <= a.M && (a.Cin & (KC - 1)) == 0 && !HSP_DBG(a, 512);  // wave-uniform
       if (fast) {
-        const float* const wtile = a.w + m0;
+        const float* const wtile = wb + m0;
         const float* const xtile = xb + p0a;
         const int xcs = (int)a.x_cs;
         const unsigned wofs = 4u * (unsigned)((lane / PR::CPR) * a.w_ld + (lane % PR::CPR) * 4);

@@ -125,6 +125,12 @@ class AMPBlock1(nn.Module):
                               weight_norm=True)
         self.convs1 = nn.ModuleList([mk(d) for d in dilation])
         self.convs2 = nn.ModuleList([mk(1) for _ in dilation])
+        # (round 4) long kernels over many channels also carry their frequency-domain form (hip_layers.Conv1d.enable_fft:
+        # overlap-save with a 128-point DFT, 2.2 multiply-adds per output and channel pair instead of k); forward()
+        # takes it where it is the faster one (fft_wins)
+        for c in list(self.convs1) + list(self.convs2):
+            if fft_eligible(channels, kernel_size, c.dilation):
+                c.enable_fft()
         self.num_layers = len(self.convs1) + len(self.convs2)
         self.activations = nn.ModuleList([
             Activation1d(activation=activations.SnakeBeta(channels, alpha_logscale=True)) for _ in range(self.num_layers)])
@@ -145,11 +151,28 @@ class AMPBlock1(nn.Module):
                     torch.cuda.current_stream(x.device).wait_event(before_last)
                 x = c2(xt, act1d=a2, **kw)
             else:
-                xt = a2(c1(a1(x)))
+                xa = a1(x)
+                xt = a2(c1.forward_fft(xa) if fft_wins(c1, xa) else c1(xa))
                 if last and before_last is not None:
                     torch.cuda.current_stream(x.device).wait_event(before_last)
-                x = c2(xt, **kw)
+                x = c2.forward_fft(xt, **kw) if fft_wins(c2, xt) else c2(xt, **kw)
         return x
+
+
+# Where the frequency-domain form of an AMP conv beats the direct MFMA conv (tools/fftconv_bench.py, B = 32, same box;
+# profiles/r04_fftconv_bench.txt): k = 11 from 256 channels (1.4-1.9 x), k = 7 at 512 channels and dilation 1 (1.26 x).
+# The channel product shrinks 5.0 x (k = 11) / 3.3 x (k = 7); what the two transforms cost grows with the tensor, not
+# with C^2, so the gain rises with the channel count.  HSP_FFT_CONV=0 switches the form off (A/B runs, parity tests
+# of both forms).
+FFT_CONV = os.environ.get("HSP_FFT_CONV", "1") == "1"
+
+
+def fft_eligible(channels: int, k: int, dilation: int) -> bool:
+    return (k >= 11 and channels >= 256) or (k >= 7 and channels >= 512 and dilation == 1)
+
+
+def fft_wins(conv, x) -> bool:
+    return FFT_CONV and getattr(conv, "_wf", None) is not None and x.stride(2) == 1
 
 
 # The parallel AMP blocks of a stage are independent chains of six launches each.  They are

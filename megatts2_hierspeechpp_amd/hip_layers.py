@@ -43,6 +43,32 @@ def _zeros(device) -> torch.Tensor:
     return z
 
 
+_DFT = {}
+
+
+def _dft_tables(device):
+    """(F, Finv): the 128 x 128 forward / inverse real-DFT matrices of csrc/hsp_dftseg.hip (include/hsp.h: row r < 64 =
+    Re(bin r), row 64 = Nyquist, rows > 64 = Im(bin r - 64)), built in float64, once per device."""
+    t = _DFT.get(device)
+    if t is None:
+        n = 128
+        i = np.arange(n, dtype=np.float64)
+        f = np.zeros((n, n))
+        finv = np.zeros((n, n))
+        for r in range(n):
+            if r < 64:
+                f[r] = np.cos(2 * np.pi * r * i / n)
+                finv[:, r] = (1.0 if r == 0 else 2.0) / n * np.cos(2 * np.pi * r * i / n)
+            elif r == 64:
+                f[r] = np.cos(np.pi * i)
+                finv[:, r] = np.cos(np.pi * i) / n
+            else:
+                f[r] = -np.sin(2 * np.pi * (r - 64) * i / n)
+                finv[:, r] = -2.0 / n * np.sin(2 * np.pi * (r - 64) * i / n)
+        t = _DFT[device] = (torch.from_numpy(f.astype(np.float32)).to(device), torch.from_numpy(finv.astype(np.float32)).to(device))
+    return t
+
+
 # SURVEY.md §8(b) names its minimum C ABI (hsp_conv1d_f32, hsp_convtr1d_f32, hsp_wn_layer_f32,
 # hsp_layernorm_modulate_f32).  Those entry points dispatch to the kernel-level ones this module calls by
 # default; with SURVEY_ABI set (HSP_SURVEY_ABI=1) every launch goes through them instead - same kernels, same
@@ -349,7 +375,17 @@ class Conv1d(_ConvBase):
         fused = self.__dict__.get("_pre_norm") is not None
         return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias or fused else []) + \
             ([("c1", self.cout)] if fused else []) + \
-            ([("wt", self.cout * self.cin)] if self.__dict__.get("_rowmajor") else [])
+            ([("wt", self.cout * self.cin)] if self.__dict__.get("_rowmajor") else []) + \
+            ([("wf", 64 * 4 * self.cin * self.cout)] if self.__dict__.get("_fft") else [])
+
+    def enable_fft(self):
+        """Also pack the frequency-domain form of this same-length stride-1 conv (round 4, csrc/hsp_dftseg.hip): per
+        frequency bin of a 128-point transform the real block matrix [[Wr, Wi], [-Wi, Wr]] of conj(rfft(w)); bin 0
+        holds DC and Nyquist.  ``forward_fft`` then computes the conv as forward DFT -> one batched 1x1 product -> inverse
+        DFT: 2.2 multiply-adds per output and channel pair instead of k."""
+        assert self.stride == 1 and self.rows == L.ROWS_PLAIN and self.cin == self.cout and 2 <= self.k <= 64
+        assert self.padding * 2 == (self.k - 1) * self.dilation, "same-length conv"
+        self.__dict__["_fft"] = True
 
     def hsp_fill(self, arena, materialize):
         if self.__dict__.get("_stacked_elsewhere"):
@@ -359,11 +395,25 @@ class Conv1d(_ConvBase):
         self._b = arena.view(self, "b") if self.has_bias or fused else None
         self._c1 = arena.view(self, "c1") if fused else None
         self._wt = arena.view(self, "wt").view(self.cout, self.cin) if self.__dict__.get("_rowmajor") else None
+        self._wf = arena.view(self, "wf") if self.__dict__.get("_fft") else None
         if materialize:
             w = self._folded()
             if self._wt is not None:
                 assert not fused
                 self._wt.copy_(w.reshape(self.cout, self.cin))
+            if self._wf is not None:
+                # conj(rfft(w)) per (co, ci) in float64; packed per bin as w[ci'][m'] (the conv kernel's [Cin][M] layout)
+                Cc = self.cin
+                wf = torch.fft.rfft(torch.nn.functional.pad(w.double(), (0, 128 - self.k)), dim=2)     # [co, ci, 65]
+                wr, wi = wf.real.permute(2, 1, 0), wf.imag.permute(2, 1, 0)                               # [bin, ci, co]
+                blk = self._wf.view(64, 2 * Cc, 2 * Cc)
+                blk[:, :Cc, :Cc] = wr[:64].float()          # Yr += Wr Xr
+                blk[:, Cc:, :Cc] = wi[:64].float()          # Yr += Wi Xi
+                blk[:, :Cc, Cc:] = -wi[:64].float()         # Yi -= Wi Xr
+                blk[:, Cc:, Cc:] = wr[:64].float()          # Yi += Wr Xi
+                blk[0, Cc:, :Cc] = 0.0                      # bin 0: DC (part 0) and Nyquist (part 1) do not mix
+                blk[0, :Cc, Cc:] = 0.0
+                blk[0, Cc:, Cc:] = wr[64].float()
             if fused:
                 g, beta = self._ln_params()
                 w2 = w.reshape(self.cout, self.cin).double()
@@ -377,6 +427,61 @@ class Conv1d(_ConvBase):
             _gather(w, conv_pack_map(self.cout, self.cin, self.k, self.row_map), self._w)
             if self._b is not None and not fused:
                 self._b.copy_(self._bias_src())
+
+    def forward_fft(self, x, *, res=None, out=None, accumulate=False, post_scale=1.0):
+        """The conv in its frequency-domain form (enable_fft()): three launches -- forward DFT of 128-sample segments,
+        ONE 1x1 product over the 64 bins on the conv kernel (hsp_conv1d_args.w_bs), inverse DFT with the conv's epilogue
+        (bias, residual, running sum, post_scale).  x [B, C, L] with unit time stride."""
+        self._require_ready()
+        B, Cc, Lx = x.shape
+        assert Cc == self.cin and x.stride(2) == 1 and self._wf is not None
+        d, k = self.dilation, self.k
+        hop = 129 - k
+        nseg = -(-(-(-Lx // d)) // hop)
+        Np = _round_up(B * d * nseg, 4)
+        f, finv = _dft_tables(x.device)
+        xf = torch.empty(64, 2 * Cc, Np, dtype=torch.float32, device=x.device)
+        yf = torch.empty(64, 2 * Cc, Np, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(B, Cc, Lx, dtype=torch.float32, device=x.device)
+        assert out.shape == (B, Cc, Lx) and out.stride(2) == 1 and (res is None or (res.shape == out.shape and res.stride(2) == 1))
+        da = L.DftSegArgs()
+        da.x, da.x_bs, da.x_cs = L.fptr(x), x.stride(0), x.stride(1)
+        da.y, da.y_bs, da.y_cs = L.fptr(out), out.stride(0), out.stride(1)
+        da.B, da.C, da.L, da.k, da.dil, da.pad, da.nseg, da.Np = B, Cc, Lx, k, d, self.padding, nseg, Np
+        da.xf, da.xf_bs, da.dft = L.fptr(xf), xf.stride(0), L.fptr(f)
+        hook = LAUNCH_HOOK
+        if hook is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(L.lib().hsp_dftseg_fwd_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_fwd_f32")
+        if hook is not None:
+            e1.record()
+            hook("hsp_dftseg_fwd_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
+        a = L.Conv1dArgs()
+        a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xf), xf.stride(0), xf.stride(1), 1
+        a.B, a.Cin, a.Lin = 64, 2 * Cc, Np
+        a.w, a.K, a.dil, a.pad, a.stride = L.fptr(self._wf), 1, 1, 0, 1
+        a.M, a.w_ld, a.w_bs = 2 * Cc, 2 * Cc, 4 * Cc * Cc
+        a.zeros = L.fptr(_zeros(x.device))
+        _set_out(a, yf, 64, 2 * Cc, Np)
+        a.ncols, a.rows, a.scale, a.post_scale = Np, L.ROWS_PLAIN, 1.0, 1.0
+        # algorithmic flops / bytes of the conv this launch stands for are booked on the channel product
+        _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * B * Cc * Cc * k * Lx,
+                4 * B * Cc * Lx * (2 + bool(res is not None) + 2 * bool(accumulate)) + 4 * k * Cc * Cc)
+        da.xf, da.xf_bs, da.dft = L.fptr(yf), yf.stride(0), L.fptr(finv)
+        da.bias = L.fptr(self._b) if self._b is not None else None
+        if res is not None:
+            da.res, da.res_bs, da.res_cs = L.fptr(res), res.stride(0), res.stride(1)
+        da.accumulate, da.post_scale = int(bool(accumulate)), float(post_scale)
+        if hook is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(L.lib().hsp_dftseg_inv_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_inv_f32")
+        if hook is not None:
+            e1.record()
+            hook("hsp_dftseg_inv_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
+        return out
 
     # ----------------------------------------------------------------------------
     def forward(self, x, *, act1d=None, lrelu: Optional[float] = None, silu_in=False, act=L.ACT_NONE, cbias=None,

@@ -779,6 +779,39 @@ def test_fused_attention_projection_vs_torch(H, D, B, Tq, Tk, form, device):
         _close(y[0].cpu().numpy(), full[:, :, T - 1].t().numpy(), f"mha_proj last B={B} T={T}")
 
 
+@pytest.mark.parametrize("C_,k,d,L,B", [(32, 11, 1, 500, 2), (32, 7, 3, 333, 2), (128, 11, 5, 1000, 1), (48, 11, 3, 118, 3),
+                                        (64, 7, 1, 122, 1), (32, 3, 5, 37, 2), (128, 7, 5, 4000, 2)])
+def test_frequency_domain_conv_vs_torch(C_, k, d, L, B, device):
+    """Conv1d.forward_fft -- overlap-save with a 128-point DFT (hsp_dftseg_fwd_f32, one batched 1x1 product over the 64
+    bins, hsp_dftseg_inv_f32) -- against torch's direct conv in float64, with the epilogue forms the AMP blocks use
+    (bias; bias + residual; bias + residual + running sum * 1/3: hierspeechpp_speechsynthesizer.py:375-392,440-446), and
+    against the direct MFMA conv of the same layer.  Lengths on / off the segment grid, every dilation of the blocks."""
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    g = torch.Generator().manual_seed(100 * k + d + L)
+    lay = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
+    with torch.no_grad():
+        for p_ in lay.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g))
+        lay.weight_g.fill_(0.5)
+    lay.enable_fft()
+    w = (lay.weight_g.data * lay.weight_v.data / lay.weight_v.data.flatten(1).norm(dim=1).view(-1, 1, 1)).double()
+    bias = lay.bias.data.clone().double()
+    finalize(lay, device)
+    x = torch.randn(B, C_, L, generator=g)
+    res = torch.randn(B, C_, L, generator=g)
+    prev = torch.randn(B, C_, L, generator=g)
+    ref = torch.nn.functional.conv1d(x.double(), w, bias, dilation=d, padding=(k - 1) * d // 2)
+    dx = x.to(device)
+    got = lay.forward_fft(dx).cpu()
+    direct = lay(dx).cpu()
+    _close(got.numpy(), ref.float().numpy(), f"fft conv C={C_} k={k} d={d} L={L}")
+    assert float((got - direct).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    got = lay.forward_fft(dx, res=res.to(device)).cpu()
+    _close(got.numpy(), (ref + res.double()).float().numpy(), "fft conv + residual")
+    got = lay.forward_fft(dx, res=res.to(device), out=prev.clone().to(device), accumulate=True, post_scale=1.0 / 3).cpu()
+    _close(got.numpy(), ((ref + res.double() + prev.double()) / 3).float().numpy(), "fft conv + residual + running sum")
+
+
 def test_long_prompts_have_no_attention_ceiling(device):
     """A 60-s prompt mel through the StyleEncoder (3 000 frames, ragged pair) and the denoiser's conformer block with
     3 200 frames on its attention axis (a 20-s prompt: denoiser/conformer.py:45-60 runs nn.MultiheadAttention along

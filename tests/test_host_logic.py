@@ -166,6 +166,9 @@ def test_ctypes_structs_match_the_header(tmp_path):
     fields_p = [f for f, _ in _lib.MhaProjArgs._fields_]
     lines += ['printf("%zu\\n", sizeof(hsp_mha_proj_args));']
     lines += [f'printf("%zu\\n", offsetof(hsp_mha_proj_args, {f}));' for f in fields_p]
+    fields_d = [f for f, _ in _lib.DftSegArgs._fields_]
+    lines += ['printf("%zu\\n", sizeof(hsp_dftseg_args));']
+    lines += [f'printf("%zu\\n", offsetof(hsp_dftseg_args, {f}));' for f in fields_d]
     lines += ["return 0;}"]
     src.write_text("\n".join(lines))
     exe = tmp_path / "abi"
@@ -174,6 +177,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     want = [ctypes.sizeof(_lib.Conv1dArgs)] + [getattr(_lib.Conv1dArgs, f).offset for f in fields_c]
     want += [ctypes.sizeof(_lib.MhaArgs)] + [getattr(_lib.MhaArgs, f).offset for f in fields_m]
     want += [ctypes.sizeof(_lib.MhaProjArgs)] + [getattr(_lib.MhaProjArgs, f).offset for f in fields_p]
+    want += [ctypes.sizeof(_lib.DftSegArgs)] + [getattr(_lib.DftSegArgs, f).offset for f in fields_d]
     assert vals == want
 
 
