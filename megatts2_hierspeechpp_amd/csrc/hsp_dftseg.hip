@@ -33,53 +33,98 @@ typedef float ds_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DS_N = 128;
 #define DS_ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
 
-// A workgroup owns `cg` channel rows of one utterance.  Its GEMM columns are the (channel, phase, segment) triples of
-// those rows, flattened -- col = (ch * d + p) * nseg + s -- so that a 32-column MFMA block is full whatever nseg is
-// (L = 800 at dilation 5 has TWO segments per phase: one block per (channel, phase) ran the matrix cores 16 x idle).
+// A workgroup owns `cg` channel rows of one utterance over a CHUNK of S consecutive segments (of every phase): the input
+// samples those segments read -- padded-time range [d s0 hop, d ((s0 + S - 1) hop + 128)) -- are one contiguous stretch
+// of every row, and so are the outputs they produce, [d s0 hop, d (s0 + S) hop).  Its GEMM columns are the (channel,
+// phase, segment) triples, flattened -- col = (ch * d + p) * S + s -- so that a 32-column MFMA block is full whatever
+// the segment count is (L = 800 at dilation 5 has TWO segments per phase).  Any length: the chunk bounds the LDS.
 struct DsCol {
   int ch, p, s;
   bool ok;
 };
-__device__ __forceinline__ DsCol ds_col(int col, int ncols, int d, int nseg) {
+__device__ __forceinline__ DsCol ds_col(int col, int ncols, int d, int S) {
   DsCol c;
   c.ok = col < ncols;
   const int cc = c.ok ? col : ncols - 1;
-  const int per = d * nseg;
+  const int per = d * S;
   c.ch = cc / per;
   const int rem = cc - c.ch * per;
-  c.p = rem / nseg;
-  c.s = rem - c.p * nseg;
+  c.p = rem / S;
+  c.s = rem - c.p * S;
   return c;
 }
 
-__global__ __launch_bounds__(256) void dftseg_fwd_kernel(const hsp_dftseg_args a, int cg, int pitch, int ngrp) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch]: zero-padded input rows
-  const int b = blockIdx.x / ngrp, c0 = (blockIdx.x % ngrp) * cg;
-  const int ncg = min(cg, a.C - c0);                            // channel rows of this workgroup
+struct DsGeom {
+  int cg, S, pitch, ngrp, nchunk;
+};
+
+__global__ __launch_bounds__(256) void dftseg_fwd_kernel(const hsp_dftseg_args a, const DsGeom G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch]: zero-padded input stretch of every row
+  const int id = blockIdx.x;
+  const int b = id / G.ngrp, c0 = (id % G.ngrp) * G.cg;
+  const int ncg = min(G.cg, a.C - c0);                          // channel rows of this workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
-  const int hop = DS_N - (a.k - 1), d = a.dil;
-  // A fragments: rows 32 wave + l32 of the forward matrix, taps 2 ks + half
+  const int hop = DS_N - (a.k - 1), d = a.dil, pitch = G.pitch;
+  // A fragments: rows 32 wave + l32 of the forward matrix, taps 2 ks + half -- fetched once, used for every chunk of the
+  // rows (a workgroup per chunk re-fetched these 64 KB for three column blocks of work: measured 1.4 x slower)
   float fa[64];
   {
     const float* frow = a.dft + (32 * wave + l32) * DS_N + half;
 #pragma unroll
     for (int ks = 0; ks < 64; ++ks) fa[ks] = frow[2 * ks];
   }
+  for (int sc = 0; sc < G.nchunk; ++sc) {
+  const int s0 = sc * G.S, S = min(G.S, a.nseg - s0);           // this chunk's segments
+  if (sc) __syncthreads();                                      // the previous chunk's stretch has been read
+  // ---- stage the stretch: row[j] = xpad[t0 + j], xpad = the conv's zero-padded input.  Sixteen loads per thread in
+  // flight (a load per loop iteration waits one L2 round trip each: that was most of the first version's time).
+  const int t0 = d * s0 * hop - a.pad;                          // input index of row[0]
+  const int len = d * ((S - 1) * hop + DS_N);
+  const bool vec = ((a.L | (int)a.x_bs | (int)a.x_cs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;   // uniform
   for (int ch = 0; ch < ncg; ++ch) {
     const float* xr = a.x + (int64_t)b * a.x_bs + (int64_t)(c0 + ch) * a.x_cs;
     float* row = lds + ch * pitch;
-    for (int t = tid; t < pitch; t += 256) {
-      const int ti = t - a.pad;
-      const float v = xr[min(max(ti, 0), a.L - 1)];           // unconditional load, selected below
-      row[t] = (ti >= 0 && ti < a.L) ? v : 0.0f;
+    if (vec) {
+      // aligned 16-B loads of the input groups that overlap the stretch (its start t0 is odd: four scalar LDS writes
+      // each); the padding on either side is zero-filled
+      for (int j = tid; j < min(-t0, len); j += 256) row[j] = 0.0f;
+      for (int j = max(a.L - t0, 0) + tid; j < len; j += 256) row[j] = 0.0f;
+      const int g_lo = max(t0, 0) >> 2, g_hi = (min(t0 + len, a.L) + 3) >> 2;       // input 4-groups [g_lo, g_hi)
+      for (int g0 = g_lo; g0 < g_hi; g0 += 256 * 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(xr + 4 * min(g0 + tid + 256 * u, g_hi - 1));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int gq = g0 + tid + 256 * u;
+          if (gq < g_hi) {
+            const int j = 4 * gq - t0;
+            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (j + i >= 0 && j + i < len) row[j + i] = e[i];
+          }
+        }
+      }
+    } else {
+      for (int j0 = 0; j0 < len; j0 += 256 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = xr[min(max(t0 + j0 + tid + 256 * u, 0), a.L - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + tid + 256 * u, ti = t0 + j;
+          if (j < len) row[j] = (ti >= 0 && ti < a.L) ? v[u] : 0.0f;
+        }
+      }
     }
   }
   __syncthreads();
-  const int ncols = ncg * d * a.nseg;
+  const int ncols = ncg * d * S;
   const int step = 2 * d;                                      // floats between the taps of consecutive k-steps
   for (int cb = 0; cb < ncols; cb += 32) {
-    const DsCol q = ds_col(cb + l32, ncols, d, a.nseg);
+    const DsCol q = ds_col(cb + l32, ncols, d, S);
     const float* bp = lds + q.ch * pitch + q.p + d * (q.s * hop + half);
     ds_f32x16 acc;
 #pragma unroll
@@ -87,7 +132,7 @@ __global__ __launch_bounds__(256) void dftseg_fwd_kernel(const hsp_dftseg_args a
 #pragma unroll
     for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * step], acc, 0, 0, 0);
     if (q.ok) {
-      float* op = a.xf + (int64_t)(c0 + q.ch) * a.Np + (b * d + q.p) * a.nseg + q.s;
+      float* op = a.xf + (int64_t)(c0 + q.ch) * a.Np + (b * d + q.p) * a.nseg + s0 + q.s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wave + DS_ACC_ROW(r, half);        // 0..63: Re(bin), 64..127: Im(bin - 64) (64: Nyquist)
@@ -95,15 +140,17 @@ __global__ __launch_bounds__(256) void dftseg_fwd_kernel(const hsp_dftseg_args a
       }
     }
   }
+  }   // chunks
 }
 
-__global__ __launch_bounds__(256) void dftseg_inv_kernel(const hsp_dftseg_args a, int cg, int pitch, int ngrp) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch]: the output rows
-  const int b = blockIdx.x / ngrp, c0 = (blockIdx.x % ngrp) * cg;
-  const int ncg = min(cg, a.C - c0);
+__global__ __launch_bounds__(256) void dftseg_inv_kernel(const hsp_dftseg_args a, const DsGeom G, int nbuf) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch] output stretch of every row | B buffers
+  const int id = blockIdx.x;
+  const int b = id / G.ngrp, c0 = (id % G.ngrp) * G.cg;
+  const int ncg = min(G.cg, a.C - c0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
-  const int hop = DS_N - (a.k - 1), d = a.dil;
+  const int hop = DS_N - (a.k - 1), d = a.dil, pitch = G.pitch;
   // A fragments: rows (time samples of a segment) 32 wave + l32 of the inverse matrix, spectrum rows 2 ks + half
   float fa[64];
   {
@@ -111,73 +158,100 @@ __global__ __launch_bounds__(256) void dftseg_inv_kernel(const hsp_dftseg_args a
 #pragma unroll
     for (int ks = 0; ks < 64; ++ks) fa[ks] = frow[2 * ks];
   }
-  const int ncols = ncg * d * a.nseg;
-  // spectrum row r = 2 ks + half: bin r & 63, part r >> 6 -> k-steps 0..31 read the real parts, 32..63 the imaginary.
-  // The 64 loads of a column block are requested one block AHEAD of the MFMAs that consume them.
-  auto request = [&](int cb, float (&fb)[64]) __attribute__((always_inline)) {
-    const DsCol q = ds_col(cb + l32, ncols, d, a.nseg);
-    const float* re = a.xf + (int64_t)half * a.xf_bs + (int64_t)(c0 + q.ch) * a.Np + (b * d + q.p) * a.nseg + q.s;
-    const float* im = re + (int64_t)a.C * a.Np;
+  for (int sc = 0; sc < G.nchunk; ++sc) {
+  const int s0 = sc * G.S, S = min(G.S, a.nseg - s0);
+  if (sc) __syncthreads();                                      // the previous chunk's outputs have left the stretch
+  const int tb = d * s0 * hop;                                  // output index of row[0] (a multiple of 4: S is even)
+  const int tl = min(a.L - tb, d * S * hop);                    // outputs of this chunk
+  const int ncols = ncg * d * S;
+  // B operand: the 128 spectrum rows (row r: bin r & 63, part r >> 6) x 32 columns of a column block.  All four waves
+  // multiply the SAME fragments (they differ in their rows of the inverse matrix), so the block is staged through LDS
+  // once -- wave w fetches the rows 32 w .. 32 w + 31, one row pair per instruction, two 128-B runs each.
+  float* const bbuf = lds + G.cg * pitch;                       // [nbuf][128][32]
+  auto fetch = [&](int cb, float (&v)[16]) __attribute__((always_inline)) {
+    const DsCol q = ds_col(cb + l32, ncols, d, S);
+    const float* src = a.xf + (int64_t)(c0 + q.ch) * a.Np + (b * d + q.p) * a.nseg + s0 + q.s;
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
-      fb[ks] = re[(int64_t)(2 * ks) * a.xf_bs];
-      fb[32 + ks] = im[(int64_t)(2 * ks) * a.xf_bs];
+    for (int u = 0; u < 16; ++u) {
+      const int r = 32 * wave + 2 * u + half;                   // spectrum row
+      v[u] = src[(int64_t)(r & 63) * a.xf_bs + (int64_t)(r >> 6) * a.C * a.Np];
     }
   };
-  float f0[64], f1[64];
-  request(0, f0);
-  auto consume = [&](int cb, const float (&fb)[64]) __attribute__((always_inline)) {
+  auto stash = [&](int buf, const float (&v)[16]) __attribute__((always_inline)) {
+    float* dst = bbuf + buf * (128 * 32) + l32;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dst[(32 * wave + 2 * u + half) * 32] = v[u];
+  };
+  auto consume = [&](int cb, int buf) __attribute__((always_inline)) {
+    const float* bp = bbuf + buf * (128 * 32) + half * 32 + l32;
     ds_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], fb[ks], acc, 0, 0, 0);
-    const DsCol q = ds_col(cb + l32, ncols, d, a.nseg);
+    for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * 64], acc, 0, 0, 0);
+    const DsCol q = ds_col(cb + l32, ncols, d, S);
     if (q.ok) {
       float* row = lds + q.ch * pitch;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = 32 * wave + DS_ACC_ROW(r, half);          // time inside the segment: the first hop are valid
-        const int t = q.p + d * (q.s * hop + i);
-        if (i < hop && t < a.L) row[t] = acc[r];
+        const int j = q.p + d * (q.s * hop + i);                // index inside the chunk's stretch
+        if (i < hop && j < tl) row[j] = acc[r];
       }
     }
   };
-  for (int cb = 0; cb < ncols; cb += 64) {
-    if (cb + 32 < ncols) request(cb + 32, f1);
-    consume(cb, f0);
-    if (cb + 32 < ncols) {
-      if (cb + 64 < ncols) request(cb + 64, f0);
-      consume(cb + 32, f1);
+  {
+    float v[16];
+    fetch(0, v);
+    stash(0, v);
+    __syncthreads();
+    int buf = 0;
+    for (int cb = 0; cb < ncols; cb += 32) {
+      const bool more = cb + 32 < ncols;                        // workgroup-uniform
+      if (more) fetch(cb + 32, v);                              // in flight under this block's MFMAs
+      consume(cb, buf);
+      if (nbuf == 1) __syncthreads();                           // one buffer: everyone has read it
+      if (more) stash(nbuf == 1 ? 0 : buf ^ 1, v);
+      __syncthreads();                                          // the next block is staged
+      buf = nbuf == 1 ? 0 : buf ^ 1;
     }
   }
-  __syncthreads();
   // ---- epilogue of the conv this replaces: y = ((corr + bias + res) [+ y]) * post_scale, one coalesced pass
-  const bool vec = ((a.L | (int)a.y_bs | (int)a.y_cs | (int)a.res_bs | (int)a.res_cs) & 3) == 0 &&
+  const bool vec = ((a.L | (int)a.y_bs | (int)a.y_cs | (int)a.res_bs | (int)a.res_cs | tb) & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;   // workgroup-uniform
   for (int ch = 0; ch < ncg; ++ch) {
     const int c = c0 + ch;
     const float bz = a.bias ? a.bias[c] : 0.0f;
     const float* row = lds + ch * pitch;
-    float* yr = a.y + (int64_t)b * a.y_bs + (int64_t)c * a.y_cs;
-    const float* rr = a.res ? a.res + (int64_t)b * a.res_bs + (int64_t)c * a.res_cs : nullptr;
+    float* yr = a.y + (int64_t)b * a.y_bs + (int64_t)c * a.y_cs + tb;
+    const float* rr = a.res ? a.res + (int64_t)b * a.res_bs + (int64_t)c * a.res_cs + tb : nullptr;
     if (vec) {
-      for (int t = 4 * tid; t < a.L; t += 1024) {
-        float4 v = *reinterpret_cast<const float4*>(row + t);
-        v.x += bz, v.y += bz, v.z += bz, v.w += bz;
-        if (rr) {
-          const float4 r4 = *reinterpret_cast<const float4*>(rr + t);
-          v.x += r4.x, v.y += r4.y, v.z += r4.z, v.w += r4.w;
+      // eight 16-B groups per thread at a time: the residual / running-sum loads of all of them in flight together
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n4 = tl >> 2;                                   // (L and tb are multiples of 4: so is tl)
+      for (int j0 = 0; j0 < n4; j0 += 256 * 8) {
+        float4 r4[8], o4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = min(j0 + tid + 256 * u, n4 - 1);
+          r4[u] = rr ? *reinterpret_cast<const float4*>(rr + 4 * j) : z4;
+          o4[u] = a.accumulate ? *reinterpret_cast<const float4*>(yr + 4 * j) : z4;
         }
-        if (a.accumulate) {
-          const float4 o4 = *reinterpret_cast<const float4*>(yr + t);
-          v.x += o4.x, v.y += o4.y, v.z += o4.z, v.w += o4.w;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + tid + 256 * u;
+          if (j < n4) {
+            float4 v = *reinterpret_cast<const float4*>(row + 4 * j);
+            v.x = (v.x + bz + r4[u].x + o4[u].x) * a.post_scale;
+            v.y = (v.y + bz + r4[u].y + o4[u].y) * a.post_scale;
+            v.z = (v.z + bz + r4[u].z + o4[u].z) * a.post_scale;
+            v.w = (v.w + bz + r4[u].w + o4[u].w) * a.post_scale;
+            *reinterpret_cast<float4*>(yr + 4 * j) = v;
+          }
         }
-        v.x *= a.post_scale, v.y *= a.post_scale, v.z *= a.post_scale, v.w *= a.post_scale;
-        *reinterpret_cast<float4*>(yr + t) = v;
       }
     } else {
-      for (int t = tid; t < a.L; t += 256) {
+      for (int t = tid; t < tl; t += 256) {
         float v = row[t] + bz;
         if (rr) v += rr[t];
         if (a.accumulate) v += yr[t];
@@ -185,6 +259,7 @@ __global__ __launch_bounds__(256) void dftseg_inv_kernel(const hsp_dftseg_args a
       }
     }
   }
+  }   // chunks
 }
 
 int ds_check(const hsp_dftseg_args& a) {
@@ -196,11 +271,29 @@ int ds_check(const hsp_dftseg_args& a) {
   return 0;
 }
 
-// channel rows per workgroup: as many as fit 64 KB of LDS (at least one: up to 40 000 floats = the whole 160 KB)
-int ds_group(int pitch, int C) {
-  int cg = 16384 / pitch;
+// Chunk geometry: the LARGEST even segment count whose stretch fits the LDS budget (the whole row at the Generator's
+// lengths: one staging, no chunk barriers -- smaller chunks were measured 1.1-2 x slower), then as many channel rows as
+// still fit.  Budget: 68 KB of input stretch (forward) / 64 KB of output stretch (inverse, next to one or two 16-KB B
+// buffers): two workgroups per CU either way.
+DsGeom ds_geom(const hsp_dftseg_args& a, bool inverse) {
+  const int hop = DS_N - (a.k - 1), d = a.dil;
+  const int budget = inverse ? 16384 : 17408;
+  auto row_of = [&](int S) { return inverse ? ((d * S * hop + 3) & ~3) : d * ((S - 1) * hop + DS_N); };
+  int S = a.nseg;
+  if (row_of(S) > budget) {
+    S = inverse ? budget / (d * hop) : (budget / d - DS_N) / hop + 1;
+    S &= ~1;
+    if (S < 2) S = 2;
+  }
+  DsGeom G;
+  G.S = S;
+  G.pitch = row_of(S);
+  int cg = budget / G.pitch;
   cg = cg < 1 ? 1 : (cg > 16 ? 16 : cg);
-  return cg > C ? C : cg;
+  G.cg = cg > a.C ? a.C : cg;
+  G.nchunk = (a.nseg + S - 1) / S;
+  G.ngrp = (a.C + G.cg - 1) / G.cg;
+  return G;
 }
 }  // namespace
 
@@ -208,16 +301,14 @@ extern "C" int hsp_dftseg_fwd_f32(const hsp_dftseg_args* ap, void* stream) {
   if (!ap || !ap->x) return HSP_EINVAL;
   const hsp_dftseg_args& a = *ap;
   if (int e = ds_check(a)) return e;
-  const int hop = DS_N - (a.k - 1);
-  const int pitch = a.dil * (a.nseg * hop + DS_N);             // every tap of every segment of every phase is inside
-  if (pitch > 40000) return HSP_EINVAL;
-  const int cg = ds_group(pitch, a.C), ngrp = (a.C + cg - 1) / cg;
-  const size_t lds_bytes = (size_t)cg * pitch * sizeof(float);
+  const DsGeom G = ds_geom(a, false);
+  const size_t lds_bytes = (size_t)G.cg * G.pitch * sizeof(float);
+  const int64_t blocks = (int64_t)a.B * G.ngrp;
+  if (lds_bytes > 160 * 1024 || blocks > 0x7fffffff) return HSP_EINVAL;
   static hsp_lds_flags flags;
   if (lds_bytes > 32 * 1024)
     if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(dftseg_fwd_kernel), 160 * 1024, flags)) return e;
-  hipLaunchKernelGGL(dftseg_fwd_kernel, dim3((unsigned)(a.B * ngrp)), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a,
-                     cg, pitch, ngrp);
+  hipLaunchKernelGGL(dftseg_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a, G);
   return (int)hipGetLastError();
 }
 
@@ -225,14 +316,15 @@ extern "C" int hsp_dftseg_inv_f32(const hsp_dftseg_args* ap, void* stream) {
   if (!ap || !ap->y) return HSP_EINVAL;
   const hsp_dftseg_args& a = *ap;
   if (int e = ds_check(a)) return e;
-  const int pitch = (a.L + 3) & ~3;
-  if (pitch > 40000) return HSP_EINVAL;
-  const int cg = ds_group(pitch, a.C), ngrp = (a.C + cg - 1) / cg;
-  const size_t lds_bytes = (size_t)cg * pitch * sizeof(float);
+  const DsGeom G = ds_geom(a, true);
+  const int nbuf = ((size_t)G.cg * G.pitch + 2 * 128 * 32) * sizeof(float) <= 80 * 1024 ? 2 : 1;   // two workgroups per CU
+  const size_t lds_bytes = ((size_t)G.cg * G.pitch + nbuf * 128 * 32) * sizeof(float);
+  const int64_t blocks = (int64_t)a.B * G.ngrp;
+  if (lds_bytes > 160 * 1024 || blocks > 0x7fffffff) return HSP_EINVAL;
   static hsp_lds_flags flags;
   if (lds_bytes > 32 * 1024)
     if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(dftseg_inv_kernel), 160 * 1024, flags)) return e;
-  hipLaunchKernelGGL(dftseg_inv_kernel, dim3((unsigned)(a.B * ngrp)), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a,
-                     cg, pitch, ngrp);
+  hipLaunchKernelGGL(dftseg_inv_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a, G,
+                     nbuf);
   return (int)hipGetLastError();
 }

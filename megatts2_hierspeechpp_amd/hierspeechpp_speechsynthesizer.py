@@ -160,15 +160,18 @@ class AMPBlock1(nn.Module):
 
 
 # Where the frequency-domain form of an AMP conv beats the direct MFMA conv (tools/fftconv_bench.py, B = 32, same box;
-# profiles/r04_fftconv_bench.txt): k = 11 from 256 channels (1.4-1.9 x), k = 7 at 512 channels and dilation 1 (1.26 x).
-# The channel product shrinks 5.0 x (k = 11) / 3.3 x (k = 7); what the two transforms cost grows with the tensor, not
-# with C^2, so the gain rises with the channel count.  HSP_FFT_CONV=0 switches the form off (A/B runs, parity tests
-# of both forms).
+# profiles/r04_fftconv_bench.txt): k = 11 from 128 channels (1.39 x at 128, 1.8 x at 256, 1.5-2.1 x at 512 channels),
+# k = 7 at 256 channels (1.14-1.22 x) and at 512 channels up to dilation 3 (1.33 / 1.08 x; 0.95 x at dilation 5, where
+# L = 800 leaves two segments per phase half empty).  The channel product shrinks 5.0 x (k = 11) / 3.3 x (k = 7); what
+# the two transforms cost grows with the tensor, not with C^2, so the gain rises with the channel count -- 64 channels
+# lose (0.8 x / 0.5 x).  HSP_FFT_CONV=0 switches the form off (A/B runs, parity tests of both forms).
 FFT_CONV = os.environ.get("HSP_FFT_CONV", "1") == "1"
 
 
 def fft_eligible(channels: int, k: int, dilation: int) -> bool:
-    return (k >= 11 and channels >= 256) or (k >= 7 and channels >= 512 and dilation == 1)
+    if k >= 11:
+        return channels >= 128
+    return k >= 7 and ((256 <= channels < 512) or (channels >= 512 and dilation <= 3))
 
 
 def fft_wins(conv, x) -> bool:
