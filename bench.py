@@ -278,7 +278,8 @@ def vocoder_roofline(args, wl, result):
             tiles[len(rec)] = f"{plan[0]}x{plan[1]}"
             kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else (
                 "hsp_conv1d_mfma_f32/rgemm" if plan[2] == -1 else "hsp_conv1d_mfma_f32/bgemm")
-        rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows)))
+        rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows) if la is not None
+                    else (0, 0, 0, 0, 0, 0, 0)))
 
     Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
     hip_layers.LAUNCH_HOOK = hook
@@ -370,6 +371,21 @@ def vocoder_roofline(args, wl, result):
         "frac": fl2 / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         "note": "conv1d_mfma_kernel launches with more than 200 output columns per utterance (Generator + SourceNetwork): "
                 "the population BENCH_r02's roofline.frac was computed over; a subset of `roofline`'s launches"}
+    # (round 4) the long AMP convs run in their frequency-domain form (forward DFT, ONE batched 1x1 product over the 64
+    # bins on conv1d_mfma_kernel, inverse DFT: csrc/hsp_dftseg.hip).  `roofline` above counts the product launches with
+    # the flops they EXECUTE; here the convs they stand for: the direct form's algorithmic flops over the time of all
+    # three launches -- the rate the direct kernel would have to reach to tie (its peak is 157.3).
+    fc = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_fftconv"]
+    if fc:
+        tr = [(kind, fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind.startswith("hsp_dftseg")]
+        f_ms, f_fl = sum(m for _, _, m in fc), sum(f for f, _, _ in fc)
+        result["roofline"]["frequency_domain_convs"] = {
+            "convs_per_step": len(fc), "ms_per_step_all_three_launches": f_ms, "algorithmic_gflop_per_step": f_fl / 1e9,
+            "algorithmic_tflops": f_fl / (f_ms * 1e-3) / 1e12,
+            "transform_launches_per_step": len(tr), "transform_ms_per_step": sum(m for _, _, m in tr),
+            "transform_executed_tflops": sum(f for _, f, _ in tr) / (sum(m for _, _, m in tr) * 1e-3) / 1e12,
+            "note": "algorithmic flops of the direct convs (2 k C^2 per output) over the time of forward DFT + channel product + "
+                    "inverse DFT; the product launches are also in `roofline` with their executed flops"}
     if act_rec:
         # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
         a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)

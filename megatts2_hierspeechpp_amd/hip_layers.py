@@ -457,6 +457,7 @@ class Conv1d(_ConvBase):
         L.check(L.lib().hsp_dftseg_fwd_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_fwd_f32")
         if hook is not None:
             e1.record()
+            e_first = e0
             hook("hsp_dftseg_fwd_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
         a = L.Conv1dArgs()
         a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xf), xf.stride(0), xf.stride(1), 1
@@ -466,9 +467,10 @@ class Conv1d(_ConvBase):
         a.zeros = L.fptr(_zeros(x.device))
         _set_out(a, yf, 64, 2 * Cc, Np)
         a.ncols, a.rows, a.scale, a.post_scale = Np, L.ROWS_PLAIN, 1.0, 1.0
-        # algorithmic flops / bytes of the conv this launch stands for are booked on the channel product
-        _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * B * Cc * Cc * k * Lx,
-                4 * B * Cc * Lx * (2 + bool(res is not None) + 2 * bool(accumulate)) + 4 * k * Cc * Cc)
+        # the launches are booked with the flops / bytes they EXECUTE; the conv they stand for is reported once more, as
+        # a whole, under the kind "hsp_fftconv" (algorithmic flops and bytes of the direct form over all three launches)
+        _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * 64 * 4 * Cc * Cc * Np,
+                4 * (64 * 2 * 2 * Cc * Np + 64 * 4 * Cc * Cc))
         da.xf, da.xf_bs, da.dft = L.fptr(yf), yf.stride(0), L.fptr(finv)
         da.bias = L.fptr(self._b) if self._b is not None else None
         if res is not None:
@@ -480,7 +482,9 @@ class Conv1d(_ConvBase):
         L.check(L.lib().hsp_dftseg_inv_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_inv_f32")
         if hook is not None:
             e1.record()
-            hook("hsp_dftseg_inv_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
+            nio = 2 + bool(res is not None) + 2 * bool(accumulate)
+            hook("hsp_dftseg_inv_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx * (nio - 1) + 128 * Cc * Np), e0, e1, None)
+            hook("hsp_fftconv", 2 * B * Cc * Cc * k * Lx, 4 * B * Cc * Lx * nio + 4 * k * Cc * Cc, e_first, e1, None)
         return out
 
     # ----------------------------------------------------------------------------
