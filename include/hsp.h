@@ -454,9 +454,11 @@ int hsp_power_mel_log_f32(const float* spec, int64_t s_bs, int32_t s_ld, const f
  *   hsp_conv1d_mfma_f32  one launch: B = 64 (the bins), Cin = M = 2 C, K = 1, Lin = Np, w_bs = 4 C^2 -- per bin the real
  *                        block matrix [[Wr, Wi], [-Wi, Wr]] of conj(rfft(w, 128)) (bin 0: [[W_dc, 0], [0, W_nyquist]])
  *   hsp_dftseg_inv_f32   yf [64][2 C][Np] -> y [B][C][L] = ((corr + bias[c] + res) [+ y]) * post_scale
- * `dft` = the 128 x 128 transform matrix, row-major: forward F[row][tap] (rows 0..63 cos(2 pi r i / 128), row 64
- * (-1)^i, rows 65..127 -sin(2 pi (r - 64) i / 128)); inverse Finv[time][row] ((1 | 2) / 128 times the same).  fp32
- * arithmetic on the fp32 MFMA; against float64 as close as the direct fp32 sum (tools/fft_conv_err.py). */
+ * `dft` = the transform's constant table in device memory (HSP_DFTSEG_TABLE_FLOATS floats; hsp_dftseg_tables_f32 fills
+ * the forward and the inverse one into host buffers): the 64 x 64 matrix of the radix-2 half-length real transform in
+ * the row order the kernel's accumulator layout wants, then (cos, sin)(2 pi k / 128), k < 32.  fp32 arithmetic on the
+ * fp32 MFMA; against float64 as close as the direct fp32 sum (tools/fft_conv_err.py). */
+#define HSP_DFTSEG_TABLE_FLOATS 4160
 typedef struct hsp_dftseg_args {
   const float* x;   /* forward: input [B][C][L], unit time stride */
   int64_t x_bs, x_cs;
@@ -475,6 +477,7 @@ typedef struct hsp_dftseg_args {
 } hsp_dftseg_args;
 int hsp_dftseg_fwd_f32(const hsp_dftseg_args* a, void* stream);
 int hsp_dftseg_inv_f32(const hsp_dftseg_args* a, void* stream);
+int hsp_dftseg_tables_f32(float* fwd, float* inv); /* host buffers of HSP_DFTSEG_TABLE_FLOATS floats each */
 
 /* ------------------------------------------------ SURVEY.md §8(b) names (dispatching entry points) */
 /* The minimum export set of SURVEY.md §8(b) under its own names; each forwards to the entry points above.

@@ -17,23 +17,42 @@
 // i in [s hop, s hop + hop).  Spectrum layout: xf[bin][part * C + c][n], n = (b * d + p) * nseg + s -- for every bin a
 // [2C][Np] matrix, what the conv kernel takes as one "utterance".
 //
-// Both transforms are products with a constant 128 x 128 matrix on v_mfma_f32_32x32x2_f32 (exact fp32): a wave keeps
-// its 32 rows of the matrix in registers (64 VGPRs) for the whole launch.  That is 2 x 282 flops per sample and channel
-// -- as much as the channel product at C = 128, a quarter of it at C = 512 -- and it needs no butterfly network; a real
-// FFT in registers would remove most of it.
+// Both transforms are products with constant matrices on v_mfma_f32_32x32x2_f32 (exact fp32), split ONCE radix-2: the
+// 128-point real DFT of a segment is E[k] + W^k O[k] with E, O the 64-point real DFTs of its even / odd samples, and
+// (E[k], O[k]) also give bin 64 - k = conj(E[k] - W^k O[k]).  So the MFMA work is two 64 x 64 real products per segment
+// (half of the 128 x 128 one; the first version of this file did that: 1.3-1.5 x slower transforms) and the recombination
+// is 8 VALU operations per bin on the accumulators -- the rows of the 64-point matrix are ordered so that a lane holds
+// Re and Im of the SAME bin of both E and O (accumulator register r and r + 8).  The inverse runs the same split
+// backwards: E^[k] = X[k] + conj(X[64 - k]), O^[k] = (X[k] - conj(X[64 - k])) W^-k, formed by the threads that stage the
+// spectrum in LDS, then even / odd output samples from the 64-point inverse matrix.  A wave keeps its 32 rows of the
+// 64 x 64 matrix in registers (32 VGPRs) for the whole launch.  hsp_dftseg_tables_f32 fills both tables.
 //   forward: the input rows of a channel group are staged in LDS once (zero padding applied there), B fragments are
 //            strided LDS reads (lane = segment), the 128 spectrum rows of a segment block leave as 128-B runs;
-//   inverse: B fragments are coalesced global loads from the 128 spectrum rows, the time samples are scattered into an
-//            LDS image of the output rows (all phases), then bias / residual / running sum are applied in one
-//            coalesced pass (the epilogue of the conv this replaces: hsp_conv1d_args bias, res, accumulate, post_scale).
+//   inverse: the spectrum rows arrive as coalesced global loads, are recombined and staged through LDS as the B operand
+//            of all four waves, the time samples are scattered into an LDS image of the output rows (all phases), then
+//            bias / residual / running sum are applied in one coalesced pass (the epilogue of the conv this replaces:
+//            hsp_conv1d_args bias, res, accumulate, post_scale).
+//
+// Both kernels are PERSISTENT (two 4-wave workgroups per CU, each walking its share of the items): the table fetch and
+// the launch ramp are paid once per workgroup, not once per row, and the forward kernel loads the NEXT item's input into
+// registers before the MFMAs of this one, so the HBM round trip of the staging is off the critical path.  The spectrum
+// stores of a column block are issued one per k-step under the next block's MFMAs: as a burst behind the loop they
+// cost 2500 cycles per block (every CU bursts at the same time, and a wave that cannot issue its stores cannot issue
+// MFMAs either).  Tried and measured slower in round 4: waves split by role (four MFMA + four memory waves per CU over
+// two LDS stretches: one MFMA wave per SIMD ran at half the MFMA rate and the transform stayed at ~2.9 TB/s), smaller
+// LDS budgets for more workgroups per CU, non-temporal loads / stores, an odd LDS lane stride (no bank-conflict gain).
 #include "hsp_device.h"
+#include <algorithm>
+#include <cmath>
 
 namespace {
 typedef float ds_f32x16 __attribute__((ext_vector_type(16)));
-constexpr int DS_N = 128;
+typedef float ds_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DS_N = 128, DS_H = 64;
+constexpr int DS_MEM = 256;                                     // threads of a workgroup
 #define DS_ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
 
-// A workgroup owns `cg` channel rows of one utterance over a CHUNK of S consecutive segments (of every phase): the input
+// An item = `cg` channel rows of one utterance over a CHUNK of S consecutive segments (of every phase): the input
 // samples those segments read -- padded-time range [d s0 hop, d ((s0 + S - 1) hop + 128)) -- are one contiguous stretch
 // of every row, and so are the outputs they produce, [d s0 hop, d (s0 + S) hop).  Its GEMM columns are the (channel,
 // phase, segment) triples, flattened -- col = (ch * d + p) * S + s -- so that a 32-column MFMA block is full whatever
@@ -55,211 +74,367 @@ __device__ __forceinline__ DsCol ds_col(int col, int ncols, int d, int S) {
 }
 
 struct DsGeom {
-  int cg, S, pitch, ngrp, nchunk;
+  int cg, S, pitch, ngrp, nchunk, bufsz;                   // bufsz: floats of one stretch ([cg][pitch], 16-B multiple)
 };
+struct DsItem {
+  int b, c0, ncg, s0, S;
+};
+__device__ __forceinline__ DsItem ds_item(int item, const hsp_dftseg_args& a, const DsGeom& G) {
+  DsItem I;
+  const int id = item / G.nchunk, sc = item - id * G.nchunk;
+  I.b = id / G.ngrp;
+  I.c0 = (id - I.b * G.ngrp) * G.cg;
+  I.ncg = min(G.cg, a.C - I.c0);
+  I.s0 = sc * G.S;
+  I.S = min(G.S, a.nseg - I.s0);
+  return I;
+}
+// Role barrier: LDS traffic of this wave has landed; global loads / stores stay in flight across it (__syncthreads
+// drains vmcnt: the MFMA waves would wait for their spectrum stores, the inverse's for the next block's fetch).
+__device__ __forceinline__ void ds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(256) void dftseg_fwd_kernel(const hsp_dftseg_args a, const DsGeom G) {
+// B operands come out of LDS through inline-asm reads in a ring of three register groups, two groups ahead of the MFMAs
+// that consume them: ONE MFMA wave per SIMD has nobody to hide its LDS latency behind, and the compiler's own schedule
+// recycled two registers (read, one MFMA, wait: 1.5-2 x the MFMA time).  A group is valid behind ds_wait<N>, which
+// re-defines its registers so that the consumers carry a data dependency on the wait (hsp_conv1d_mfma_kernel.h).
+__device__ __forceinline__ unsigned ds_lds_addr(const float* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+__device__ __forceinline__ void ds_rd(float& dst, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr)); }
+template <int OFF>
+__device__ __forceinline__ void ds_rd_at(float& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offsets are 16 bits");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void ds_wait(float (&r)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(r[i]));
+}
+
+// ---------------------------------------------------------------------------------------------------------- forward
+// Staging of an item: row[j + sh] = xpad[t0 + j], xpad = the conv's zero-padded input, as a flat list of 16-B input
+// groups -- element e = ch * ng + gi is group g_lo + gi of row ch -- sixteen per thread and batch.
+struct DsStage {
+  int t0, len, sh, g_lo, ng, tot;
+};
+__device__ __forceinline__ DsStage ds_stage_of(const hsp_dftseg_args& a, const DsItem& I) {
+  const int hop = DS_N - (a.k - 1), d = a.dil;
+  DsStage s;
+  s.t0 = d * I.s0 * hop - a.pad;                                // input index of the stretch's sample 0
+  s.len = d * ((I.S - 1) * hop + DS_N);
+  s.sh = 4 + (s.t0 & 3);                                        // input 4-groups land 16-B aligned in LDS
+  s.g_lo = max(s.t0, 0) >> 2;
+  s.ng = ((min(s.t0 + s.len, a.L) + 3) >> 2) - s.g_lo;          // input 4-groups [g_lo, g_lo + ng) overlap the stretch
+  s.tot = I.ncg * s.ng;
+  return s;
+}
+__device__ __forceinline__ void ds_stage_load(const hsp_dftseg_args& a, const DsItem& I, const DsStage& s, int e0, int t,
+                                              ds_f32x4 (&v)[16]) {
+  const float* xb = a.x + (int64_t)I.b * a.x_bs + (int64_t)I.c0 * a.x_cs;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = min(e0 + t + DS_MEM * u, s.tot - 1), ch = e / s.ng, gi = e - ch * s.ng;
+    v[u] = *reinterpret_cast<const ds_f32x4*>(xb + (int64_t)ch * a.x_cs + 4 * (s.g_lo + gi));
+  }
+}
+__device__ __forceinline__ void ds_stage_write(const DsGeom& G, const DsStage& s, int e0, int t, float* buf, const ds_f32x4 (&v)[16]) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = e0 + t + DS_MEM * u, ch = min(e, s.tot - 1) / s.ng, gi = e - ch * s.ng;
+    // a group may hang over either end of the stretch by up to three samples: the rows have that slack
+    if (e < s.tot) *reinterpret_cast<ds_f32x4*>(buf + ch * G.pitch + s.sh - s.t0 + 4 * (s.g_lo + gi)) = v[u];
+  }
+}
+
+__global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) void dftseg_fwd_kernel(const hsp_dftseg_args a, const DsGeom G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch]: zero-padded input stretch of every row
-  const int id = blockIdx.x;
-  const int b = id / G.ngrp, c0 = (id % G.ngrp) * G.cg;
-  const int ncg = min(G.cg, a.C - c0);                          // channel rows of this workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
   const int hop = DS_N - (a.k - 1), d = a.dil, pitch = G.pitch;
-  // A fragments: rows 32 wave + l32 of the forward matrix, taps 2 ks + half -- fetched once, used for every chunk of the
-  // rows (a workgroup per chunk re-fetched these 64 KB for three column blocks of work: measured 1.4 x slower)
-  float fa[64];
+  const int nitems = a.B * G.ngrp * G.nchunk;
+  const int nmine = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid is <= nitems
+  // Two waves share a 32-column block: wave half `wh` owns the bins 16 wh .. 16 wh + 15 of E and O (rows 32 wh + l32 of
+  // the 64 x 64 table: Re of those bins in tile rows 0..15, Im in 16..31), i.e. the output bins k and 64 - k; the wave
+  // pairs (0, 1) and (2, 3) work on alternate column blocks.  A fragments: taps 2 ks + half, fetched once per launch.
+  // Accumulator register r (and r + 8) holds bin 16 wh + DS_ACC_ROW(r, half); its twiddle W^k comes out of LDS.
+  const int wh = wave & 1, pairw = wave >> 1;
+  float fa[32];
   {
-    const float* frow = a.dft + (32 * wave + l32) * DS_N + half;
+    const float* frow = a.dft + (32 * wh + l32) * DS_H + half;
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) fa[ks] = frow[2 * ks];
+    for (int ks = 0; ks < 32; ++ks) fa[ks] = frow[2 * ks];
   }
-  for (int sc = 0; sc < G.nchunk; ++sc) {
-  const int s0 = sc * G.S, S = min(G.S, a.nseg - s0);           // this chunk's segments
-  if (sc) __syncthreads();                                      // the previous chunk's stretch has been read
-  // ---- stage the stretch: row[j] = xpad[t0 + j], xpad = the conv's zero-padded input.  Sixteen loads per thread in
-  // flight (a load per loop iteration waits one L2 round trip each: that was most of the first version's time).
-  const int t0 = d * s0 * hop - a.pad;                          // input index of row[0]
-  const int len = d * ((S - 1) * hop + DS_N);
+  float* const twl = lds + G.bufsz;                             // (cos | sin)(2 pi k / 128), k < 32, behind the stretch
+  if (tid < 64) twl[tid] = a.dft[DS_H * DS_H + tid];
+  // the previous column block's outputs of this lane (bin register r: X[kb] Re, Im, X[64 - kb] Re, Im) and where they go:
+  // 32-bit byte offsets into the spectrum (the host checks that it is below 4 GB), lane part in two registers -- bins
+  // kb = lanek + c_r count up from lb1, bins 64 - kb down from lb2 -- and the register's part c_r xf_bs uniform (the
+  // 32 full 64-bit offsets, hoisted out of the item loop by the compiler, cost 64 registers and with them the second
+  // workgroup of the CU).
+  float ov[32];
+  bool pok = false;
+  unsigned lb1 = 0, lb2 = 0, lbz = 0;
+  const unsigned rowb = 4u * (unsigned)a.xf_bs, imb = 4u * (unsigned)(a.C * a.Np);   // bytes of a bin plane / to part 1 (Im)
+  const int lanek = 16 * wh + 4 * half;
+  auto put = [&](int i) __attribute__((always_inline)) {
+    const int r = i >> 2, w = i & 3;
+    const unsigned cr = (unsigned)((r & 3) + 8 * (r >> 2)) * rowb;   // uniform
+    unsigned off = w < 2 ? lb1 + cr : lb2 - cr;
+    if (r == 0 && w >= 2) off = lanek == 0 ? lbz : off;         // bin 0's lane: X[32] where the others put bin 64 - kb
+    if (w & 1) off += imb;
+    if (pok) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.xf) + off) = ov[i];
+  };
   const bool vec = ((a.L | (int)a.x_bs | (int)a.x_cs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;   // uniform
-  for (int ch = 0; ch < ncg; ++ch) {
-    const float* xr = a.x + (int64_t)b * a.x_bs + (int64_t)(c0 + ch) * a.x_cs;
-    float* row = lds + ch * pitch;
+  // Persistent workgroups, two per CU.  The first sixteen 16-B groups per thread of the NEXT item (all of it at the
+  // Generator's shapes) are loaded into registers before this item's MFMAs and written to LDS behind them: the HBM round
+  // trip of the staging is off the critical path.
+  DsItem I = ds_item(blockIdx.x, a, G);
+  DsStage sg = ds_stage_of(a, I);
+  ds_f32x4 pv[16];
+  if (vec) ds_stage_load(a, I, sg, 0, tid, pv);
+  for (int it = 0; it < nmine; ++it) {
+    if (it) ds_barrier();                                       // the previous item's stretch has been read
+    // ---- finish the staging of item `it`
     if (vec) {
-      // aligned 16-B loads of the input groups that overlap the stretch (its start t0 is odd: four scalar LDS writes
-      // each); the padding on either side is zero-filled
-      for (int j = tid; j < min(-t0, len); j += 256) row[j] = 0.0f;
-      for (int j = max(a.L - t0, 0) + tid; j < len; j += 256) row[j] = 0.0f;
-      const int g_lo = max(t0, 0) >> 2, g_hi = (min(t0 + len, a.L) + 3) >> 2;       // input 4-groups [g_lo, g_hi)
-      for (int g0 = g_lo; g0 < g_hi; g0 += 256 * 16) {
-        float4 v[16];
+      ds_stage_write(G, sg, 0, tid, lds, pv);
+      for (int e0 = DS_MEM * 16; e0 < sg.tot; e0 += DS_MEM * 16) {
+        ds_f32x4 v[16];
+        ds_stage_load(a, I, sg, e0, tid, v);
+        ds_stage_write(G, sg, e0, tid, lds, v);
+      }
+      for (int ch = 0; ch < I.ncg; ++ch) {                      // the conv's zero padding on either side
+        float* row = lds + ch * pitch + sg.sh;
+        for (int j = tid; j < min(-sg.t0, sg.len); j += DS_MEM) row[j] = 0.0f;
+        for (int j = max(a.L - sg.t0, 0) + tid; j < sg.len; j += DS_MEM) row[j] = 0.0f;
+      }
+    } else {
+      for (int ch = 0; ch < I.ncg; ++ch) {
+        const float* xr = a.x + (int64_t)I.b * a.x_bs + (int64_t)(I.c0 + ch) * a.x_cs;
+        float* row = lds + ch * pitch + sg.sh;
+        for (int j0 = 0; j0 < sg.len; j0 += DS_MEM * 16) {
+          float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(xr + 4 * min(g0 + tid + 256 * u, g_hi - 1));
+          for (int u = 0; u < 16; ++u) v[u] = xr[min(max(sg.t0 + j0 + tid + DS_MEM * u, 0), a.L - 1)];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int gq = g0 + tid + 256 * u;
-          if (gq < g_hi) {
-            const int j = 4 * gq - t0;
-            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (j + i >= 0 && j + i < len) row[j + i] = e[i];
+          for (int u = 0; u < 16; ++u) {
+            const int j = j0 + tid + DS_MEM * u, ti = sg.t0 + j;
+            if (j < sg.len) row[j] = (ti >= 0 && ti < a.L) ? v[u] : 0.0f;
           }
         }
       }
-    } else {
-      for (int j0 = 0; j0 < len; j0 += 256 * 16) {
-        float v[16];
+    }
+    ds_barrier();
+    const DsItem Ic = I;
+    const int shc = sg.sh;
+    if (it + 1 < nmine) {                                       // the next item's loads go out now
+      I = ds_item(blockIdx.x + (it + 1) * gridDim.x, a, G);
+      sg = ds_stage_of(a, I);
+      if (vec) ds_stage_load(a, I, sg, 0, tid, pv);
+    }
+    // ---- the transform of item `it`
+    const int S = Ic.S, ncols = Ic.ncg * d * S;
+    const float* buf = lds + shc;                               // sample 0 of row 0
+    const int step = 4 * d;                                     // floats between the even (odd) taps of consecutive k-steps
+    for (int cb = 32 * pairw; cb < ncols; cb += 64) {
+      const DsCol q = ds_col(cb + l32, ncols, d, S);
+      const float* bp = buf + q.ch * pitch + q.p + d * (q.s * hop + 2 * half);
+      ds_f32x16 ae, ao;                                         // E = F64 x[even], O = F64 x[odd]
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = xr[min(max(t0 + j0 + tid + 256 * u, 0), a.L - 1)];
+      for (int r = 0; r < 16; ++r) ae[r] = ao[r] = 0.0f;
+      // groups of four k-steps: (even, odd) taps 4 (4 g + j) + 2 half (+ 1) of the segment, d floats apart
+      float rb[2][8];
+      unsigned pe = ds_lds_addr(bp), po = pe + 4u * d;
+      const unsigned st = 4u * step;
+      auto issue = [&](float (&r)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int j = j0 + tid + 256 * u, ti = t0 + j;
-          if (j < len) row[j] = (ti >= 0 && ti < a.L) ? v[u] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+          ds_rd(r[2 * j], pe);
+          ds_rd(r[2 * j + 1], po);
+          pe += st;
+          po += st;
+        }
+      };
+      issue(rb[0]);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        ds_wait<0>(rb[g & 1]);
+        if (g + 1 < 8) issue(rb[(g + 1) & 1]);                  // in flight under this group's eight MFMAs
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ae = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[4 * g + j], rb[g & 1][2 * j], ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[4 * g + j], rb[g & 1][2 * j + 1], ao, 0, 0, 0);
+          put(4 * g + j);                                       // one of the previous block's 32 stores
         }
       }
-    }
-  }
-  __syncthreads();
-  const int ncols = ncg * d * S;
-  const int step = 2 * d;                                      // floats between the taps of consecutive k-steps
-  for (int cb = 0; cb < ncols; cb += 32) {
-    const DsCol q = ds_col(cb + l32, ncols, d, S);
-    const float* bp = lds + q.ch * pitch + q.p + d * (q.s * hop + half);
-    ds_f32x16 acc;
+      // X[kb] = E + W^kb O, X[64 - kb] = conj(E - W^kb O) for the eight bins of this lane; bin 0's lane holds (E[0],
+      // E[32]) and (O[0], O[32]), all real: DC = E0 + O0 and Nyquist = E0 - O0 share bin slot 0, and X[32] = E[32] -
+      // i O[32] goes where the other lanes put bin 64 - kb.  The values wait in registers: their stores are issued one
+      // per k-step under the NEXT block's MFMAs (as a burst behind the loop they cost 2500 cycles per block -- every
+      // CU bursts at the same time, and a wave that cannot issue its stores cannot issue its MFMAs either).
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * step], acc, 0, 0, 0);
-    if (q.ok) {
-      float* op = a.xf + (int64_t)(c0 + q.ch) * a.Np + (b * d + q.p) * a.nseg + s0 + q.s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wave + DS_ACC_ROW(r, half);        // 0..63: Re(bin), 64..127: Im(bin - 64) (64: Nyquist)
-        op[(int64_t)(row & 63) * a.xf_bs + (int64_t)(row >> 6) * a.C * a.Np] = acc[r];
+      for (int r = 0; r < 8; ++r) {
+        const float er = ae[r], ei = ae[r + 8], orr = ao[r], oi = ao[r + 8];
+        const float wc = twl[lanek + (r & 3) + 8 * (r >> 2)], ws = twl[32 + lanek + (r & 3) + 8 * (r >> 2)];
+        const float tr = wc * orr + ws * oi, ti = wc * oi - ws * orr;
+        const bool z = r == 0 && wh == 0 && half == 0;
+        ov[4 * r + 0] = er + tr;
+        ov[4 * r + 1] = z ? er - tr : ei + ti;
+        ov[4 * r + 2] = z ? ei : er - tr;
+        ov[4 * r + 3] = z ? -oi : ti - ei;
+      }
+      {
+        const unsigned colb = 4u * (unsigned)((Ic.c0 + q.ch) * a.Np + (Ic.b * d + q.p) * a.nseg + Ic.s0 + q.s);
+        pok = q.ok;
+        lb1 = colb + (unsigned)lanek * rowb;
+        lb2 = colb + (unsigned)(64 - lanek) * rowb;
+        lbz = colb + 32u * rowb;
       }
     }
   }
-  }   // chunks
+#pragma unroll
+  for (int i = 0; i < 32; ++i) put(i);                          // the last block's outputs
 }
 
-__global__ __launch_bounds__(256) void dftseg_inv_kernel(const hsp_dftseg_args a, const DsGeom G, int nbuf) {
+// ---------------------------------------------------------------------------------------------------------- inverse
+// Epilogue of the conv this replaces, y = ((corr + bias + res) [+ y]) * post_scale, out of the LDS stretch: slice
+// `sl` of `nsl` of the item's rows, by `nthr` threads.  W floats per thread and strip; eight strips per thread at a
+// time, the residual / running-sum loads of all of them in flight together.
+template <int W>
+__device__ __forceinline__ void ds_inv_epilogue(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const float* buf,
+                                                int sl, int nsl, int t, int nthr, int tb, int tl) {
+  typedef float vec_t __attribute__((ext_vector_type(W)));
+  const int nel = tl / W;                                       // elements per row
+  const int R = (nel + nthr - 1) / nthr;                        // strips per row
+  const int T = I.ncg * R;
+  const int q_lo = (int)((int64_t)sl * T / nsl), q_hi = (int)((int64_t)(sl + 1) * T / nsl);
+  for (int q0 = q_lo; q0 < q_hi; q0 += 8) {
+    vec_t r4[8], o4[8];
+    float bz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = min(q0 + u, q_hi - 1), ch = q / R, c = I.c0 + ch;
+      const int j = min((q - ch * R) * nthr + t, nel - 1);
+      const int64_t yo = (int64_t)I.b * a.y_bs + (int64_t)c * a.y_cs + tb + W * j;
+      bz[u] = a.bias ? a.bias[c] : 0.0f;
+      r4[u] = a.res ? *reinterpret_cast<const vec_t*>(a.res + (int64_t)I.b * a.res_bs + (int64_t)c * a.res_cs + tb + W * j) : vec_t(0.0f);
+      o4[u] = a.accumulate ? *reinterpret_cast<const vec_t*>(a.y + yo) : vec_t(0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u, ch = min(q, q_hi - 1) / R;
+      const int j = (q - ch * R) * nthr + t;
+      if (q < q_hi && j < nel) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(buf + ch * G.pitch + W * j);
+        *reinterpret_cast<vec_t*>(a.y + (int64_t)I.b * a.y_bs + (int64_t)(I.c0 + ch) * a.y_cs + tb + W * j) =
+            (v + bz[u] + r4[u] + o4[u]) * a.post_scale;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_args a, const DsGeom G, int nbuf) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch] output stretch of every row | B buffers
-  const int id = blockIdx.x;
-  const int b = id / G.ngrp, c0 = (id % G.ngrp) * G.cg;
-  const int ncg = min(G.cg, a.C - c0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
   const int hop = DS_N - (a.k - 1), d = a.dil, pitch = G.pitch;
-  // A fragments: rows (time samples of a segment) 32 wave + l32 of the inverse matrix, spectrum rows 2 ks + half
-  float fa[64];
+  const int nitems = a.B * G.ngrp * G.nchunk;                   // persistent workgroups, as the forward kernel
+  // All four waves work on ONE 32-column block: wave (eo, wh) produces the even (eo = 0) or odd time samples
+  // 2 (32 wh + row) + eo of its segments from E^ (O^).  A fragments: rows 32 wh + l32 of the 64 x 64 inverse table
+  // (time j x packed spectrum slot: slot t < 32 = Re of bin t, slot 32 = bin 32 (real), slot 32 + t = Im of bin t).
+  const int wh = wave & 1, eo = wave >> 1;
+  float fa[32], twc[4], tws[4];
   {
-    const float* frow = a.dft + (32 * wave + l32) * DS_N + half;
+    const float* frow = a.dft + (32 * wh + l32) * DS_H + half;
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) fa[ks] = frow[2 * ks];
+    for (int ks = 0; ks < 32; ++ks) fa[ks] = frow[2 * ks];
+    // staging: this thread recombines the bins kf(u) = 8 wave + 4 half + u, u < 4, of column l32
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      twc[u] = a.dft[DS_H * DS_H + 8 * wave + 4 * half + u];
+      tws[u] = a.dft[DS_H * DS_H + 32 + 8 * wave + 4 * half + u];
+    }
   }
-  for (int sc = 0; sc < G.nchunk; ++sc) {
-  const int s0 = sc * G.S, S = min(G.S, a.nseg - s0);
-  if (sc) __syncthreads();                                      // the previous chunk's outputs have left the stretch
-  const int tb = d * s0 * hop;                                  // output index of row[0] (a multiple of 4: S is even)
-  const int tl = min(a.L - tb, d * S * hop);                    // outputs of this chunk
-  const int ncols = ncg * d * S;
-  // B operand: the 128 spectrum rows (row r: bin r & 63, part r >> 6) x 32 columns of a column block.  All four waves
-  // multiply the SAME fragments (they differ in their rows of the inverse matrix), so the block is staged through LDS
-  // once -- wave w fetches the rows 32 w .. 32 w + 31, one row pair per instruction, two 128-B runs each.
-  float* const bbuf = lds + G.cg * pitch;                       // [nbuf][128][32]
-  auto fetch = [&](int cb, float (&v)[16]) __attribute__((always_inline)) {
-    const DsCol q = ds_col(cb + l32, ncols, d, S);
-    const float* src = a.xf + (int64_t)(c0 + q.ch) * a.Np + (b * d + q.p) * a.nseg + s0 + q.s;
+  float* const bbuf = lds + G.bufsz;                            // [nbuf][E^ | O^][64 slots][32 columns]
+  // the epilogue runs in the scalar form unless every row it touches is 16-B addressable (workgroup-uniform)
+  const bool vec0 = ((a.L | (int)a.y_bs | (int)a.y_cs | (int)a.res_bs | (int)a.res_cs) & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const DsItem I = ds_item(item, a, G);
+    const int S = I.S, ncols = I.ncg * d * S, nblk = (ncols + 31) >> 5;
+    const int tb = d * I.s0 * hop;                              // output index of row[0]
+    const int tl = min(a.L - tb, d * S * hop);                  // outputs of this chunk
+    if (item != (int)blockIdx.x) ds_barrier();                  // the previous item's outputs have left the stretch
+    // B operand of a column block: [E^ | O^][64 slots][32 columns], the same for all four waves, so it is staged through
+    // LDS once.  A thread fetches X[k] and X[64 - k] (bin 0's thread: DC | Nyquist and X[32]) of four bins of one column
+    // -- every load instruction two 128-B runs -- and stores E^ = X[k] + conj(X[64 - k]), O^ = (X[k] - conj(X[64 - k]))
+    // W^-k (the factor 1/2 is in the table).
+    auto fetch = [&](int cb, float (&v)[16]) __attribute__((always_inline)) {
+      const DsCol q = ds_col(cb + l32, ncols, d, S);
+      const float* src = a.xf + (int64_t)(I.c0 + q.ch) * a.Np + (I.b * d + q.p) * a.nseg + I.s0 + q.s;
+      const int64_t im = (int64_t)a.C * a.Np;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int r = 32 * wave + 2 * u + half;                   // spectrum row
-      v[u] = src[(int64_t)(r & 63) * a.xf_bs + (int64_t)(r >> 6) * a.C * a.Np];
-    }
-  };
-  auto stash = [&](int buf, const float (&v)[16]) __attribute__((always_inline)) {
-    float* dst = bbuf + buf * (128 * 32) + l32;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) dst[(32 * wave + 2 * u + half) * 32] = v[u];
-  };
-  auto consume = [&](int cb, int buf) __attribute__((always_inline)) {
-    const float* bp = bbuf + buf * (128 * 32) + half * 32 + l32;
-    ds_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * 64], acc, 0, 0, 0);
-    const DsCol q = ds_col(cb + l32, ncols, d, S);
-    if (q.ok) {
-      float* row = lds + q.ch * pitch;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = 32 * wave + DS_ACC_ROW(r, half);          // time inside the segment: the first hop are valid
-        const int j = q.p + d * (q.s * hop + i);                // index inside the chunk's stretch
-        if (i < hop && j < tl) row[j] = acc[r];
+      for (int u = 0; u < 4; ++u) {
+        const int kf = 8 * wave + 4 * half + u, k2 = kf == 0 ? 32 : 64 - kf;
+        v[4 * u + 0] = src[(int64_t)kf * a.xf_bs];
+        v[4 * u + 1] = src[(int64_t)kf * a.xf_bs + im];
+        v[4 * u + 2] = src[(int64_t)k2 * a.xf_bs];
+        v[4 * u + 3] = src[(int64_t)k2 * a.xf_bs + im];
       }
-    }
-  };
-  {
+    };
+    auto stash = [&](int buf, const float (&v)[16]) __attribute__((always_inline)) {
+      float* dst = bbuf + buf * (128 * 32) + l32;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kf = 8 * wave + 4 * half + u;
+        const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
+        const float dr = xr - yr, di = xi + yi;                 // X[k] - conj(X[64 - k])
+        const bool z = u == 0 && kf == 0;                       // (DC, Nyquist, Re X[32], Im X[32]): E^0 E^32 O^0 O^32 real
+        dst[kf * 32] = z ? xr + xi : xr + yr;                   // Re E^[k]
+        dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;          // Im E^[k]             (slot 32: E^[32] = 2 Re X[32])
+        dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];       // Re O^[k]
+        dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];    // Im O^[k]  (slot 32: O^[32] = -2 Im X[32])
+      }
+    };
+    auto consume = [&](int cb, int buf) __attribute__((always_inline)) {
+      const float* bp = bbuf + buf * (128 * 32) + eo * (64 * 32) + half * 32 + l32;
+      ds_f32x16 acc, acc2;                                      // two chains: even / odd k-steps
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 32; ks += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * 64], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks + 1], bp[ks * 64 + 64], acc2, 0, 0, 0);
+      }
+      const DsCol q = ds_col(cb + l32, ncols, d, S);
+      if (q.ok) {
+        float* row = lds + q.ch * pitch;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 2 * (32 * wh + DS_ACC_ROW(r, half)) + eo;   // time inside the segment: the first hop are valid
+          const int j = q.p + d * (q.s * hop + i);              // index inside the chunk's stretch
+          if (i < hop && j < tl) row[j] = acc[r] + acc2[r];
+        }
+      }
+    };
     float v[16];
     fetch(0, v);
     stash(0, v);
-    __syncthreads();
+    ds_barrier();
     int buf = 0;
-    for (int cb = 0; cb < ncols; cb += 32) {
-      const bool more = cb + 32 < ncols;                        // workgroup-uniform
-      if (more) fetch(cb + 32, v);                              // in flight under this block's MFMAs
-      consume(cb, buf);
-      if (nbuf == 1) __syncthreads();                           // one buffer: everyone has read it
+    for (int blk = 0; blk < nblk; ++blk) {
+      const bool more = blk + 1 < nblk;                         // workgroup-uniform
+      if (more) fetch(32 * blk + 32, v);                        // in flight under this block's MFMAs
+      consume(32 * blk, buf);
+      if (nbuf == 1) ds_barrier();                              // one buffer: everyone has read it
       if (more) stash(nbuf == 1 ? 0 : buf ^ 1, v);
-      __syncthreads();                                          // the next block is staged
+      ds_barrier();                                             // the next block is staged, the last one scattered
       buf = nbuf == 1 ? 0 : buf ^ 1;
     }
+    if (vec0 && ((tb | tl) & 3) == 0) ds_inv_epilogue<4>(a, G, I, lds, 0, 1, tid, DS_MEM, tb, tl);
+    else ds_inv_epilogue<1>(a, G, I, lds, 0, 1, tid, DS_MEM, tb, tl);
   }
-  // ---- epilogue of the conv this replaces: y = ((corr + bias + res) [+ y]) * post_scale, one coalesced pass
-  const bool vec = ((a.L | (int)a.y_bs | (int)a.y_cs | (int)a.res_bs | (int)a.res_cs | tb) & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;   // workgroup-uniform
-  for (int ch = 0; ch < ncg; ++ch) {
-    const int c = c0 + ch;
-    const float bz = a.bias ? a.bias[c] : 0.0f;
-    const float* row = lds + ch * pitch;
-    float* yr = a.y + (int64_t)b * a.y_bs + (int64_t)c * a.y_cs + tb;
-    const float* rr = a.res ? a.res + (int64_t)b * a.res_bs + (int64_t)c * a.res_cs + tb : nullptr;
-    if (vec) {
-      // eight 16-B groups per thread at a time: the residual / running-sum loads of all of them in flight together
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int n4 = tl >> 2;                                   // (L and tb are multiples of 4: so is tl)
-      for (int j0 = 0; j0 < n4; j0 += 256 * 8) {
-        float4 r4[8], o4[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = min(j0 + tid + 256 * u, n4 - 1);
-          r4[u] = rr ? *reinterpret_cast<const float4*>(rr + 4 * j) : z4;
-          o4[u] = a.accumulate ? *reinterpret_cast<const float4*>(yr + 4 * j) : z4;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + tid + 256 * u;
-          if (j < n4) {
-            float4 v = *reinterpret_cast<const float4*>(row + 4 * j);
-            v.x = (v.x + bz + r4[u].x + o4[u].x) * a.post_scale;
-            v.y = (v.y + bz + r4[u].y + o4[u].y) * a.post_scale;
-            v.z = (v.z + bz + r4[u].z + o4[u].z) * a.post_scale;
-            v.w = (v.w + bz + r4[u].w + o4[u].w) * a.post_scale;
-            *reinterpret_cast<float4*>(yr + 4 * j) = v;
-          }
-        }
-      }
-    } else {
-      for (int t = tid; t < tl; t += 256) {
-        float v = row[t] + bz;
-        if (rr) v += rr[t];
-        if (a.accumulate) v += yr[t];
-        yr[t] = v * a.post_scale;
-      }
-    }
-  }
-  }   // chunks
 }
 
 int ds_check(const hsp_dftseg_args& a) {
@@ -272,43 +447,97 @@ int ds_check(const hsp_dftseg_args& a) {
 }
 
 // Chunk geometry: the LARGEST even segment count whose stretch fits the LDS budget (the whole row at the Generator's
-// lengths: one staging, no chunk barriers -- smaller chunks were measured 1.1-2 x slower), then as many channel rows as
-// still fit.  Budget: 68 KB of input stretch (forward) / 64 KB of output stretch (inverse, next to one or two 16-KB B
-// buffers): two workgroups per CU either way.
+// lengths: one staging per row -- smaller chunks were measured 1.1-2 x slower), then as many channel rows as still fit,
+// preferring a count that fills the last MFMA column block (112 columns of 16 rows x 7 segments leave an eighth of
+// the fourth block empty, 18 rows fill it).  Budget: 68 KB of input stretch (forward) / 64 KB of output stretch
+// (inverse, next to one or two 16-KB B buffers): two workgroups per CU either way.
 DsGeom ds_geom(const hsp_dftseg_args& a, bool inverse) {
   const int hop = DS_N - (a.k - 1), d = a.dil;
   const int budget = inverse ? 16384 : 17408;
-  auto row_of = [&](int S) { return inverse ? ((d * S * hop + 3) & ~3) : d * ((S - 1) * hop + DS_N); };
+  auto row_of = [&](int S) { return inverse ? ((d * S * hop + 3) & ~3) : ((d * ((S - 1) * hop + DS_N) + 12 + 3) & ~3); };
   int S = a.nseg;
   if (row_of(S) > budget) {
-    S = inverse ? budget / (d * hop) : (budget / d - DS_N) / hop + 1;
-    S &= ~1;
-    if (S < 2) S = 2;
+    int smax = inverse ? budget / (d * hop) : ((budget - 15) / d - DS_N) / hop + 1;
+    smax &= ~1;
+    if (smax < 2) smax = 2;
+    const int nch = (a.nseg + smax - 1) / smax;                 // equal chunks (28 segments: 14 + 14, not 26 + 2)
+    S = ((a.nseg + nch - 1) / nch + 1) & ~1;
+    if (S > smax) S = smax;
   }
   DsGeom G;
   G.S = S;
   G.pitch = row_of(S);
-  int cg = budget / G.pitch;
-  cg = cg < 1 ? 1 : (cg > 16 ? 16 : cg);
-  G.cg = cg > a.C ? a.C : cg;
+  int cmax = budget / G.pitch;
+  cmax = cmax < 1 ? 1 : (cmax > 32 ? 32 : cmax);
+  cmax = cmax > a.C ? a.C : cmax;
+  const int quantum = inverse ? 32 : 64;                        // columns of one round of the MFMA waves
+  int best = cmax;
+  double best_fill = 0.0;
+  for (int cg = cmax; cg >= (cmax + 1) / 2; --cg) {
+    const int ncols = cg * d * S;
+    const double fill = (double)ncols / (quantum * ((ncols + quantum - 1) / quantum));
+    if (fill > best_fill + 1e-9) best_fill = fill, best = cg;
+  }
+  G.cg = best;
+  G.bufsz = (G.cg * G.pitch + 3) & ~3;
   G.nchunk = (a.nseg + S - 1) / S;
   G.ngrp = (a.C + G.cg - 1) / G.cg;
   return G;
 }
+
+// the persistent grid: the workgroups the device keeps resident at this LDS footprint
+int64_t ds_resident(size_t lds_bytes) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  const int per = (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+  return (int64_t)cus * per;
+}
 }  // namespace
+
+extern "C" int hsp_dftseg_tables_f32(float* fwd, float* inv) {
+  if (!fwd || !inv) return HSP_EINVAL;
+  const double w = 2.0 * 3.14159265358979323846 / DS_H;
+  for (int wh = 0; wh < 2; ++wh)
+    for (int j = 0; j < 32; ++j) {
+      const int k = 16 * wh + (j & 15);                         // forward row 32 wh + j: Re (j < 16) / Im of bin k of the
+      float* row = fwd + (32 * wh + j) * DS_H;                  // 64-point transform; Im of bin 0 is replaced by bin 32
+      for (int n = 0; n < DS_H; ++n)
+        row[n] = (float)(j < 16 ? cos(w * k * n) : (k == 0 ? ((n & 1) ? -1.0 : 1.0) : -sin(w * k * n)));
+    }
+  for (int j = 0; j < DS_H; ++j)                                // inverse: time j x slot (half of the usual scale: the
+    for (int t = 0; t < DS_H; ++t) {                            // staged operand is twice E^ / O^)
+      const int k = t & 31;
+      double v;
+      if (k == 0) v = (t == 0 ? 1.0 : ((j & 1) ? -1.0 : 1.0)) / 128.0;
+      else v = (t < 32 ? cos(w * k * j) : -sin(w * k * j)) / 64.0;
+      inv[j * DS_H + t] = (float)v;
+    }
+  for (int k = 0; k < 32; ++k) {                                // W^k of the 128-point transform: (cos, sin)(2 pi k / 128)
+    fwd[DS_H * DS_H + k] = inv[DS_H * DS_H + k] = (float)cos(w * k / 2);
+    fwd[DS_H * DS_H + 32 + k] = inv[DS_H * DS_H + 32 + k] = (float)sin(w * k / 2);
+  }
+  return 0;
+}
 
 extern "C" int hsp_dftseg_fwd_f32(const hsp_dftseg_args* ap, void* stream) {
   if (!ap || !ap->x) return HSP_EINVAL;
   const hsp_dftseg_args& a = *ap;
   if (int e = ds_check(a)) return e;
   const DsGeom G = ds_geom(a, false);
-  const size_t lds_bytes = (size_t)G.cg * G.pitch * sizeof(float);
-  const int64_t blocks = (int64_t)a.B * G.ngrp;
-  if (lds_bytes > 160 * 1024 || blocks > 0x7fffffff) return HSP_EINVAL;
+  const size_t lds_bytes = ((size_t)G.bufsz + 64) * sizeof(float);
+  const int64_t items = (int64_t)a.B * G.ngrp * G.nchunk;
+  if (lds_bytes > 160 * 1024 || items > 0x7fffffff) return HSP_EINVAL;
+  if (a.xf_bs * 64 * 4 > 0xffffffffll) return HSP_EINVAL;      // the kernel addresses the spectrum with 32-bit byte offsets
+  const int64_t blocks = std::min<int64_t>(items, ds_resident(lds_bytes));
   static hsp_lds_flags flags;
   if (lds_bytes > 32 * 1024)
     if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(dftseg_fwd_kernel), 160 * 1024, flags)) return e;
-  hipLaunchKernelGGL(dftseg_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a, G);
+  hipLaunchKernelGGL(dftseg_fwd_kernel, dim3((unsigned)blocks), dim3(DS_MEM), lds_bytes, static_cast<hipStream_t>(stream), a, G);
   return (int)hipGetLastError();
 }
 
@@ -317,14 +546,15 @@ extern "C" int hsp_dftseg_inv_f32(const hsp_dftseg_args* ap, void* stream) {
   const hsp_dftseg_args& a = *ap;
   if (int e = ds_check(a)) return e;
   const DsGeom G = ds_geom(a, true);
-  const int nbuf = ((size_t)G.cg * G.pitch + 2 * 128 * 32) * sizeof(float) <= 80 * 1024 ? 2 : 1;   // two workgroups per CU
-  const size_t lds_bytes = ((size_t)G.cg * G.pitch + nbuf * 128 * 32) * sizeof(float);
-  const int64_t blocks = (int64_t)a.B * G.ngrp;
-  if (lds_bytes > 160 * 1024 || blocks > 0x7fffffff) return HSP_EINVAL;
+  const int nbuf = ((size_t)G.bufsz + 2 * 128 * 32) * sizeof(float) <= 80 * 1024 ? 2 : 1;   // two workgroups per CU
+  const size_t lds_bytes = ((size_t)G.bufsz + nbuf * 128 * 32) * sizeof(float);
+  const int64_t items = (int64_t)a.B * G.ngrp * G.nchunk;
+  if (lds_bytes > 160 * 1024 || items > 0x7fffffff) return HSP_EINVAL;
+  const int64_t blocks = std::min<int64_t>(items, ds_resident(lds_bytes));
   static hsp_lds_flags flags;
   if (lds_bytes > 32 * 1024)
     if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(dftseg_inv_kernel), 160 * 1024, flags)) return e;
-  hipLaunchKernelGGL(dftseg_inv_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a, G,
+  hipLaunchKernelGGL(dftseg_inv_kernel, dim3((unsigned)blocks), dim3(DS_MEM), lds_bytes, static_cast<hipStream_t>(stream), a, G,
                      nbuf);
   return (int)hipGetLastError();
 }

@@ -169,9 +169,10 @@ FFT_CONV = os.environ.get("HSP_FFT_CONV", "1") == "1"
 
 
 def fft_eligible(channels: int, k: int, dilation: int) -> bool:
+    """Where the frequency-domain form wins at the Generator's shapes (profiles/r04_fftconv_bench.txt, 32 x 4 s)."""
     if k >= 11:
-        return channels >= 128
-    return k >= 7 and ((256 <= channels < 512) or (channels >= 512 and dilation <= 3))
+        return channels >= 128 or (channels >= 64 and dilation <= 3)
+    return k >= 7 and (channels >= 256 or (channels >= 128 and dilation <= 3))
 
 
 def fft_wins(conv, x) -> bool:

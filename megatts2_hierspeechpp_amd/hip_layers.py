@@ -47,25 +47,15 @@ _DFT = {}
 
 
 def _dft_tables(device):
-    """(F, Finv): the 128 x 128 forward / inverse real-DFT matrices of csrc/hsp_dftseg.hip (include/hsp.h: row r < 64 =
-    Re(bin r), row 64 = Nyquist, rows > 64 = Im(bin r - 64)), built in float64, once per device."""
+    """(fwd, inv): the constant tables of csrc/hsp_dftseg.hip (include/hsp.h hsp_dftseg_tables_f32: the 64 x 64 matrix of
+    the radix-2 half-length transform + the 128-point twiddles), filled by the library, once per device."""
     t = _DFT.get(device)
     if t is None:
-        n = 128
-        i = np.arange(n, dtype=np.float64)
-        f = np.zeros((n, n))
-        finv = np.zeros((n, n))
-        for r in range(n):
-            if r < 64:
-                f[r] = np.cos(2 * np.pi * r * i / n)
-                finv[:, r] = (1.0 if r == 0 else 2.0) / n * np.cos(2 * np.pi * r * i / n)
-            elif r == 64:
-                f[r] = np.cos(np.pi * i)
-                finv[:, r] = np.cos(np.pi * i) / n
-            else:
-                f[r] = -np.sin(2 * np.pi * (r - 64) * i / n)
-                finv[:, r] = -2.0 / n * np.sin(2 * np.pi * (r - 64) * i / n)
-        t = _DFT[device] = (torch.from_numpy(f.astype(np.float32)).to(device), torch.from_numpy(finv.astype(np.float32)).to(device))
+        n = 4160  # HSP_DFTSEG_TABLE_FLOATS
+        f = np.zeros(n, dtype=np.float32)
+        finv = np.zeros(n, dtype=np.float32)
+        L.check(L.lib().hsp_dftseg_tables_f32(f.ctypes.data, finv.ctypes.data), "hsp_dftseg_tables_f32")
+        t = _DFT[device] = (torch.from_numpy(f).to(device), torch.from_numpy(finv).to(device))
     return t
 
 
@@ -458,7 +448,7 @@ class Conv1d(_ConvBase):
         if hook is not None:
             e1.record()
             e_first = e0
-            hook("hsp_dftseg_fwd_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
+            hook("hsp_dftseg_fwd_f32", 2 * 2 * 64 * 64 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
         a = L.Conv1dArgs()
         a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xf), xf.stride(0), xf.stride(1), 1
         a.B, a.Cin, a.Lin = 64, 2 * Cc, Np
@@ -483,7 +473,7 @@ class Conv1d(_ConvBase):
         if hook is not None:
             e1.record()
             nio = 2 + bool(res is not None) + 2 * bool(accumulate)
-            hook("hsp_dftseg_inv_f32", 2 * 128 * 128 * B * Cc * d * nseg, 4 * (B * Cc * Lx * (nio - 1) + 128 * Cc * Np), e0, e1, None)
+            hook("hsp_dftseg_inv_f32", 2 * 2 * 64 * 64 * B * Cc * d * nseg, 4 * (B * Cc * Lx * (nio - 1) + 128 * Cc * Np), e0, e1, None)
             hook("hsp_fftconv", 2 * B * Cc * Cc * k * Lx, 4 * B * Cc * Lx * nio + 4 * k * Cc * Cc, e_first, e1, None)
         return out
 

@@ -343,3 +343,44 @@ def test_wn_layers_and_dit_ffn_reach_their_named_entry_points_only_under_survey_
     blk(x, None, mask, mod=torch.zeros(2, 6 * 192, 1), premasked=True)
     assert [k for k, _ in seen] == ["hsp_wn_layer_f32"] * 3 + ["hsp_ffn_conv_f32"], seen
     assert seen[0][1] == [True, True, True] and seen[2][1] == [True, False, True]   # last WN layer: skip only
+
+
+def test_dftseg_tables_give_the_128_point_real_transform_and_its_inverse():
+    """hsp_dftseg_tables_f32 (host side, no GPU): the radix-2 tables of csrc/hsp_dftseg.hip, recombined exactly as the two
+    kernels do it (forward: X[k] = E[k] + W^k O[k], X[64 - k] = conj(E[k] - W^k O[k]), bin 0's lane carrying DC, Nyquist
+    and bin 32; inverse: E^ = X[k] + conj(X[64 - k]), O^ = (X[k] - conj(X[64 - k])) W^-k), are numpy's rfft / irfft."""
+    from megatts2_hierspeechpp_amd import _lib as L
+
+    f = np.zeros(4160, np.float32)
+    fi = np.zeros(4160, np.float32)
+    assert L.lib().hsp_dftseg_tables_f32(f.ctypes.data, fi.ctypes.data) == 0
+    M = f[:4096].reshape(64, 64).astype(np.float64)
+    c, s = f[4096:4128].astype(np.float64), f[4128:4160].astype(np.float64)
+    assert np.array_equal(f[4096:], fi[4096:])
+    x = np.random.default_rng(0).standard_normal(128)
+    E, O = M @ x[0::2], M @ x[1::2]
+    Xr, Xi = np.zeros(65), np.zeros(65)
+    for wh in range(2):
+        for i in range(16):
+            k = 16 * wh + i
+            er, ei, orr, oi = E[32 * wh + i], E[32 * wh + 16 + i], O[32 * wh + i], O[32 * wh + 16 + i]
+            tr, ti = c[k] * orr + s[k] * oi, c[k] * oi - s[k] * orr
+            if k == 0:
+                Xr[0], Xr[64], Xr[32], Xi[32] = er + tr, er - tr, ei, -oi
+            else:
+                Xr[k], Xi[k], Xr[64 - k], Xi[64 - k] = er + tr, ei + ti, er - tr, ti - ei
+    ref = np.fft.rfft(x)
+    assert np.abs(Xr - ref.real).max() < 2e-6 and np.abs(Xi - ref.imag).max() < 2e-6
+    Mi = fi[:4096].reshape(64, 64).astype(np.float64)
+    Eb, Ob = np.zeros(64), np.zeros(64)
+    for k in range(32):
+        if k == 0:
+            xr, xi, yr, yi = Xr[0], Xr[64], Xr[32], Xi[32]
+            Eb[0], Eb[32], Ob[0], Ob[32] = xr + xi, 2 * yr, xr - xi, -2 * yi
+        else:
+            xr, xi, yr, yi = Xr[k], Xi[k], Xr[64 - k], Xi[64 - k]
+            dr, di = xr - yr, xi + yi
+            Eb[k], Eb[32 + k], Ob[k], Ob[32 + k] = xr + yr, xi - yi, dr * c[k] - di * s[k], dr * s[k] + di * c[k]
+    y = np.zeros(128)
+    y[0::2], y[1::2] = Mi @ Eb, Mi @ Ob
+    assert np.abs(y - x).max() < 1e-6

@@ -15,6 +15,8 @@ from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--stages", action="store_true")
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--k", type=int, nargs="*", default=[11, 7, 3])
+ap.add_argument("--d", type=int, nargs="*", default=[1, 3, 5])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -39,8 +41,8 @@ def timed(fn, reps=5):
 
 print("C L k d | direct ms (TF/s) | frequency-domain ms (algorithmic TF/s) | ratio" + (" | fwd / product / inv ms" if a.stages else ""))
 for C_, L_ in ((512, 800), (256, 4000), (128, 16000), (64, 32000)):
-    for k in (11, 7, 3):
-        for d in (1, 3, 5):
+    for k in a.k:
+        for d in a.d:
             lay = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
             lay.enable_fft()
             finalize(lay, dev)
