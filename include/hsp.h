@@ -474,6 +474,12 @@ typedef struct hsp_dftseg_args {
   int64_t res_bs, res_cs;
   int32_t accumulate;
   float post_scale;
+  /* forward, optional: the anti-aliased SnakeBeta in front of the conv (Activation1d; the arguments of
+   * hsp_act1d_snakebeta_f32) applied while the input is staged -- the transform of act(x) without act(x) ever being
+   * written.  NULL act_alpha_exp = none.  Needs 16-B addressable rows (L, x_bs, x_cs multiples of 4, x 16-B aligned). */
+  const float* act_alpha_exp;
+  const float* act_beta_inv;
+  const float* act_filt;
 } hsp_dftseg_args;
 int hsp_dftseg_fwd_f32(const hsp_dftseg_args* a, void* stream);
 int hsp_dftseg_inv_f32(const hsp_dftseg_args* a, void* stream);

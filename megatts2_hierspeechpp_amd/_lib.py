@@ -86,6 +86,7 @@ class DftSegArgs(C.Structure):
         ("xf", _fp), ("xf_bs", C.c_int64), ("dft", _fp),
         ("bias", _fp), ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64),
         ("accumulate", C.c_int32), ("post_scale", C.c_float),
+        ("act_alpha_exp", _fp), ("act_beta_inv", _fp), ("act_filt", _fp),
     ]
 
 

@@ -148,6 +148,112 @@ __device__ __forceinline__ void ds_stage_write(const DsGeom& G, const DsStage& s
   }
 }
 
+// ---- the anti-aliased SnakeBeta in front of the conv (Activation1d, hierspeechpp_speechsynthesizer.py:340-392: every
+// AMP conv reads act(x)), fused into the staging: the stretch receives act(x) and the activation's own launch -- one read
+// and one write of the tensor -- goes away.  The arithmetic is act1d_seg_kernel's (hsp_pointwise.hip), on segments of
+// DA_SEG outputs: a WAVE owns a segment and its own LDS slice (raw window | 2x-rate snake signal), phases separated by
+// compiler fences only (a wave's LDS instructions retire in order).
+//   raw[j] = x[clamp(p0 - 8 + j)]                 j in [0, 256): one aligned float4 per lane
+//   a2[j]  = a[clamp(2 p0 - 5 + j, 0, 2 L - 1)]   a = snake(2 * upsampled x)
+//   y[p0 + s] = sum_k hd[k] a2[2 s + k]
+constexpr int DA_SEG = 240, DA_RAW = 256, DA_A2 = 496, DA_SLICE = DA_RAW + DA_A2;
+typedef float ds_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void da_fence() { asm volatile("" ::: "memory"); }
+struct DaItem {
+  int pa, pb, pa4, nsg, nsegs;                                  // outputs [pa, pb) of every row, segments of DA_SEG from pa4
+};
+__device__ __forceinline__ DaItem da_item(const hsp_dftseg_args& a, const DsItem& I, const DsStage& s) {
+  DaItem A;
+  A.pa = max(s.t0, 0);
+  A.pb = min(s.t0 + s.len, a.L);
+  A.pa4 = A.pa & ~3;
+  A.nsg = (A.pb - A.pa4 + DA_SEG - 1) / DA_SEG;
+  A.nsegs = I.ncg * A.nsg;
+  return A;
+}
+// the raw window of segment sI (clamped to the item's last one: always a legal address, no branch around the load)
+__device__ __forceinline__ ds_f32x4 da_load(const hsp_dftseg_args& a, const DsItem& I, const DaItem& A, int sI, int lane) {
+  const int q = min(sI, A.nsegs - 1), ch = q / A.nsg, p0 = A.pa4 + DA_SEG * (q - ch * A.nsg);
+  const float* xr = a.x + (int64_t)I.b * a.x_bs + (int64_t)(I.c0 + ch) * a.x_cs;
+  return *reinterpret_cast<const ds_f32x4*>(xr + hsp_clampi(p0 - 8 + 4 * lane, 0, a.L - 4));
+}
+// one segment: raw window in registers -> act -> the stretch (row[j + sh] = act(x)[t0 + j] for t0 + j in [pa, pb))
+__device__ __forceinline__ void da_segment(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const DsStage& s,
+                                           const DaItem& A, int sI, int lane, ds_f32x4 rv, float* slice, float* buf,
+                                           const float* flt) {
+  const int ch = sI / A.nsg, p0 = A.pa4 + DA_SEG * (sI - ch * A.nsg);
+  const int n_out = min(DA_SEG, a.L - p0);                      // a multiple of 4
+  const int c = I.c0 + ch;
+  const float kf = a.act_alpha_exp[c] * 0.318309886183790672f, kb = 0.5f * a.act_beta_inv[c];
+  float* raw = slice;
+  float* a2 = slice + DA_RAW;
+  // the taps come out of LDS for every segment (24 registers held across the MFMA loop cost the kernel its occupancy)
+  ds_f32x2 hu[6], hd[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    hu[i] = *reinterpret_cast<const ds_f32x2*>(flt + 2 * i);
+    hd[i] = *reinterpret_cast<const ds_f32x2*>(flt + 12 + 2 * i);
+  }
+  // ---- phase A: registers -> LDS (replicate padding: the clamped address was 0 or L - 4)
+  {
+    const int idx = p0 - 8 + 4 * lane;
+    ds_f32x4 t = rv;
+    t = idx < 0 ? ds_f32x4{t.x, t.x, t.x, t.x} : t;
+    t = idx >= a.L ? ds_f32x4{t.w, t.w, t.w, t.w} : t;
+    *reinterpret_cast<ds_f32x4*>(raw + 4 * lane) = t;
+  }
+  da_fence();
+  // ---- phase B: lane pair pi owns a[2q + 1 .. 2q + 4], q = p0 - 3 + 2 pi; its inputs x[q - 2 .. q + 4] = raw[2 pi + 3 ..]
+  const int npairs = (2 * n_out + 13) >> 2;                     // slots [0, 2 n_out + 10)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pi = lane + 64 * it;
+    if (pi < npairs) {
+      const ds_f32x2* rp = reinterpret_cast<const ds_f32x2*>(raw + 2 * pi + 2);
+      const ds_f32x2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      const float xv[7] = {r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+      ds_f32x2 u0 = {0.0f, 0.0f}, u1 = {0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        u0 = __builtin_elementwise_fma(ds_f32x2{xv[i], xv[i]}, hu[i], u0);
+        u1 = __builtin_elementwise_fma(ds_f32x2{xv[i + 1], xv[i + 1]}, hu[i], u1);
+      }
+      *reinterpret_cast<ds_f32x4*>(a2 + 4 * pi) =
+          ds_f32x4{hsp_snake_hw(u0.x, kf, kb), hsp_snake_hw(u0.y, kf, kb), hsp_snake_hw(u1.x, kf, kb), hsp_snake_hw(u1.y, kf, kb)};
+    }
+  }
+  da_fence();
+  // replicate padding of the 2x-rate signal: a[-5 .. -1] = a[0], a[2L .. 2L + 4] = a[2L - 1]
+  if (p0 == 0 || p0 + n_out == a.L) {
+    if (p0 == 0 && lane < 5) a2[lane] = a2[5];
+    if (p0 + n_out == a.L && lane >= 8 && lane < 13) a2[2 * n_out + lane - 3] = a2[2 * n_out + 4];
+    da_fence();
+  }
+  // ---- phase C: two outputs per lane, into the stretch
+  float* row = buf + ch * G.pitch + s.sh - s.t0;                // row[p] = sample p of the padded input
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int l2 = lane + 64 * it;
+    if (2 * l2 < n_out) {
+      const ds_f32x4* ap = reinterpret_cast<const ds_f32x4*>(a2 + 4 * l2);
+      const ds_f32x4 q0 = ap[0], q1 = ap[1], q2 = ap[2];
+      const ds_f32x2 q3 = *reinterpret_cast<const ds_f32x2*>(a2 + 4 * l2 + 12);
+      const ds_f32x2 aw[7] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}, q3};
+      ds_f32x2 s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        s0 = __builtin_elementwise_fma(aw[k], hd[k], s0);
+        s1 = __builtin_elementwise_fma(aw[k + 1], hd[k], s1);
+      }
+      const int p = p0 + 2 * l2;
+      if (p >= A.pa && p < A.pb) row[p] = s0.x + s0.y;
+      if (p + 1 >= A.pa && p + 1 < A.pb) row[p + 1] = s1.x + s1.y;
+    }
+  }
+  da_fence();                                                   // raw / a2 are rewritten by the next segment
+}
+
+template <bool ACT>
 __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) void dftseg_fwd_kernel(const hsp_dftseg_args a, const DsGeom G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [cg][pitch]: zero-padded input stretch of every row
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,14 +296,42 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // Persistent workgroups, two per CU.  The first sixteen 16-B groups per thread of the NEXT item (all of it at the
   // Generator's shapes) are loaded into registers before this item's MFMAs and written to LDS behind them: the HBM round
   // trip of the staging is off the critical path.
+  constexpr bool act = ACT;                                     // (the host asks for it on 16-B addressable rows only)
+  float* const flt = lds + G.bufsz + 64;                        // upsampling taps (x2 gain folded in, reversed) | downsampling taps
+  float* const slice = flt + 32 + wave * DA_SLICE;              // this wave's activation scratch
+  if (act && tid < 24) {
+    const int i = tid >> 1;                                     // hu[i] = 2 (filt[10 - 2 i], filt[11 - 2 i]), hd[i] = (filt[12 + 2 i], filt[13 + 2 i])
+    flt[tid] = tid < 12 ? 2.0f * a.act_filt[10 - 2 * i + (tid & 1)] : a.act_filt[tid];
+  }
+  if (act) __syncthreads();                                     // the first item's staging reads the taps
   DsItem I = ds_item(blockIdx.x, a, G);
   DsStage sg = ds_stage_of(a, I);
+  DaItem da = da_item(a, I, sg);
   ds_f32x4 pv[16];
-  if (vec) ds_stage_load(a, I, sg, 0, tid, pv);
+  auto prefetch = [&]() __attribute__((always_inline)) {
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pv[i] = da_load(a, I, da, wave + 4 * i, lane);   // this wave's first sixteen segments
+    } else if (vec) {
+      ds_stage_load(a, I, sg, 0, tid, pv);
+    }
+  };
+  prefetch();
   for (int it = 0; it < nmine; ++it) {
     if (it) ds_barrier();                                       // the previous item's stretch has been read
     // ---- finish the staging of item `it`
-    if (vec) {
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (wave + 4 * i < da.nsegs) da_segment(a, G, I, sg, da, wave + 4 * i, lane, pv[i], slice, lds, flt);
+      for (int sI = wave + 64; sI < da.nsegs; sI += 4)          // beyond the prefetch depth
+        da_segment(a, G, I, sg, da, sI, lane, da_load(a, I, da, sI, lane), slice, lds, flt);
+      for (int ch = 0; ch < I.ncg; ++ch) {                      // the conv's zero padding on either side
+        float* row = lds + ch * pitch + sg.sh;
+        for (int j = tid; j < min(-sg.t0, sg.len); j += DS_MEM) row[j] = 0.0f;
+        for (int j = max(a.L - sg.t0, 0) + tid; j < sg.len; j += DS_MEM) row[j] = 0.0f;
+      }
+    } else if (vec) {
       ds_stage_write(G, sg, 0, tid, lds, pv);
       for (int e0 = DS_MEM * 16; e0 < sg.tot; e0 += DS_MEM * 16) {
         ds_f32x4 v[16];
@@ -231,7 +365,8 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (it + 1 < nmine) {                                       // the next item's loads go out now
       I = ds_item(blockIdx.x + (it + 1) * gridDim.x, a, G);
       sg = ds_stage_of(a, I);
-      if (vec) ds_stage_load(a, I, sg, 0, tid, pv);
+      da = da_item(a, I, sg);
+      prefetch();
     }
     // ---- the transform of item `it`
     const int S = Ic.S, ncols = Ic.ncg * d * S;
@@ -529,15 +664,22 @@ extern "C" int hsp_dftseg_fwd_f32(const hsp_dftseg_args* ap, void* stream) {
   const hsp_dftseg_args& a = *ap;
   if (int e = ds_check(a)) return e;
   const DsGeom G = ds_geom(a, false);
-  const size_t lds_bytes = ((size_t)G.bufsz + 64) * sizeof(float);
+  const bool act = a.act_alpha_exp != nullptr;
+  if (act && (!a.act_beta_inv || !a.act_filt || ((a.L | (int)a.x_bs | (int)a.x_cs) & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15)))
+    return HSP_EINVAL;                                          // the fused activation wants 16-B addressable rows
+  const size_t lds_bytes = ((size_t)G.bufsz + 64 + (act ? 32 + 4 * DA_SLICE : 0)) * sizeof(float);
   const int64_t items = (int64_t)a.B * G.ngrp * G.nchunk;
   if (lds_bytes > 160 * 1024 || items > 0x7fffffff) return HSP_EINVAL;
   if (a.xf_bs * 64 * 4 > 0xffffffffll) return HSP_EINVAL;      // the kernel addresses the spectrum with 32-bit byte offsets
   const int64_t blocks = std::min<int64_t>(items, ds_resident(lds_bytes));
-  static hsp_lds_flags flags;
+  static hsp_lds_flags flags[2];
+  const void* kern = act ? reinterpret_cast<const void*>(dftseg_fwd_kernel<true>) : reinterpret_cast<const void*>(dftseg_fwd_kernel<false>);
   if (lds_bytes > 32 * 1024)
-    if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(dftseg_fwd_kernel), 160 * 1024, flags)) return e;
-  hipLaunchKernelGGL(dftseg_fwd_kernel, dim3((unsigned)blocks), dim3(DS_MEM), lds_bytes, static_cast<hipStream_t>(stream), a, G);
+    if (int e = hsp_raise_lds_limit(kern, 160 * 1024, flags[act])) return e;
+  if (act)
+    hipLaunchKernelGGL(dftseg_fwd_kernel<true>, dim3((unsigned)blocks), dim3(DS_MEM), lds_bytes, static_cast<hipStream_t>(stream), a, G);
+  else
+    hipLaunchKernelGGL(dftseg_fwd_kernel<false>, dim3((unsigned)blocks), dim3(DS_MEM), lds_bytes, static_cast<hipStream_t>(stream), a, G);
   return (int)hipGetLastError();
 }
 

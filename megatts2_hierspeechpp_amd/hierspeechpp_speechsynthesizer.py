@@ -25,6 +25,7 @@ from torch import nn
 from . import _lib as L
 from . import commons
 from . import functional as Fh
+from . import hip_layers
 from . import activations
 from . import modules
 from .alias_free_torch import Activation1d
@@ -151,11 +152,19 @@ class AMPBlock1(nn.Module):
                     torch.cuda.current_stream(x.device).wait_event(before_last)
                 x = c2(xt, act1d=a2, **kw)
             else:
-                xa = a1(x)
-                xt = a2(c1.forward_fft(xa) if fft_wins(c1, xa) else c1(xa))
-                if last and before_last is not None:
+                # a conv in its frequency-domain form applies its activation while the forward transform stages the
+                # input (hsp_dftseg_args.act_*): no launch, no act(x) in HBM
+                if fft_wins(c1, x):
+                    xt = c1.forward_fft(x, act1d=a1) if fft_act(x) else c1.forward_fft(a1(x))
+                else:
+                    xt = c1(a1(x))
+                if last and before_last is not None and not fft_wins(c2, xt):
                     torch.cuda.current_stream(x.device).wait_event(before_last)
-                x = c2.forward_fft(xt, **kw) if fft_wins(c2, xt) else c2(xt, **kw)
+                if fft_wins(c2, xt):
+                    x = c2.forward_fft(xt, act1d=a2, before_inverse=before_last if last else None, **kw) if fft_act(xt) \
+                        else c2.forward_fft(a2(xt), before_inverse=before_last if last else None, **kw)
+                else:
+                    x = c2(a2(xt), **kw)
         return x
 
 
@@ -175,8 +184,25 @@ def fft_eligible(channels: int, k: int, dilation: int) -> bool:
     return k >= 7 and (channels >= 256 or (channels >= 128 and dilation <= 3))
 
 
+def fft_min_cols(channels: int, k: int) -> int:
+    """Samples per channel (batch x length) from which the frequency-domain form wins: its product launch reads one
+    [2C][2C] matrix per bin (268 MB at 512 channels) and there are three launches, a floor that a single short utterance
+    does not amortise (profiles/r04_fftconv_batch.txt: 0.19 ms at 512 channels whatever the batch is, up to 8 x 4 s)."""
+    if k >= 11:
+        return 6400 if channels >= 512 else 8000 if channels >= 256 else 32000 if channels >= 128 else 256000
+    return 6400 if channels >= 512 else 16000 if channels >= 256 else 128000
+
+
 def fft_wins(conv, x) -> bool:
-    return FFT_CONV and getattr(conv, "_wf", None) is not None and x.stride(2) == 1
+    return (FFT_CONV and getattr(conv, "_wf", None) is not None and x.stride(2) == 1
+            and x.shape[0] * x.shape[2] >= fft_min_cols(conv.cin, conv.k))
+
+
+FFT_ACT = os.environ.get("HSP_FFT_ACT", "1") == "1"   # 0: the activation stays its own launch (A/B runs)
+
+
+def fft_act(x) -> bool:
+    return FFT_ACT and hip_layers.fft_act_fusable(x)
 
 
 # The parallel AMP blocks of a stage are independent chains of six launches each.  They are

@@ -59,6 +59,12 @@ def _dft_tables(device):
     return t
 
 
+def fft_act_fusable(x) -> bool:
+    """hsp_dftseg_args.act_*: the fused activation reads 16-B groups of every row."""
+    return (x.stride(2) == 1 and x.shape[2] % 4 == 0 and x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0
+            and x.data_ptr() % 16 == 0)
+
+
 # SURVEY.md §8(b) names its minimum C ABI (hsp_conv1d_f32, hsp_convtr1d_f32, hsp_wn_layer_f32,
 # hsp_layernorm_modulate_f32).  Those entry points dispatch to the kernel-level ones this module calls by
 # default; with SURVEY_ABI set (HSP_SURVEY_ABI=1) every launch goes through them instead - same kernels, same
@@ -418,10 +424,13 @@ class Conv1d(_ConvBase):
             if self._b is not None and not fused:
                 self._b.copy_(self._bias_src())
 
-    def forward_fft(self, x, *, res=None, out=None, accumulate=False, post_scale=1.0):
+    def forward_fft(self, x, *, res=None, out=None, accumulate=False, post_scale=1.0, act1d=None, before_inverse=None):
         """The conv in its frequency-domain form (enable_fft()): three launches -- forward DFT of 128-sample segments,
         ONE 1x1 product over the 64 bins on the conv kernel (hsp_conv1d_args.w_bs), inverse DFT with the conv's epilogue
-        (bias, residual, running sum, post_scale).  x [B, C, L] with unit time stride."""
+        (bias, residual, running sum, post_scale).  x [B, C, L] with unit time stride.  ``act1d``: the Activation1d in
+        front of the conv, applied by the forward transform while it stages its input (needs 16-B addressable rows:
+        fft_act_fusable).  ``before_inverse``: an event the stream waits on before the inverse transform, the only launch
+        that touches ``out``."""
         self._require_ready()
         B, Cc, Lx = x.shape
         assert Cc == self.cin and x.stride(2) == 1 and self._wf is not None
@@ -440,11 +449,18 @@ class Conv1d(_ConvBase):
         da.y, da.y_bs, da.y_cs = L.fptr(out), out.stride(0), out.stride(1)
         da.B, da.C, da.L, da.k, da.dil, da.pad, da.nseg, da.Np = B, Cc, Lx, k, d, self.padding, nseg, Np
         da.xf, da.xf_bs, da.dft = L.fptr(xf), xf.stride(0), L.fptr(f)
+        if act1d is not None:
+            if not fft_act_fusable(x):
+                raise L.HspError("forward_fft(act1d=...) needs 16-B addressable rows")
+            if act1d._ea is None:
+                raise L.HspError("Activation1d used before finalize()")
+            da.act_alpha_exp, da.act_beta_inv, da.act_filt = L.fptr(act1d._ea), L.fptr(act1d._binv), L.fptr(act1d._filt)
         hook = LAUNCH_HOOK
         if hook is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         L.check(L.lib().hsp_dftseg_fwd_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_fwd_f32")
+        da.act_alpha_exp = da.act_beta_inv = da.act_filt = None
         if hook is not None:
             e1.record()
             e_first = e0
@@ -461,6 +477,8 @@ class Conv1d(_ConvBase):
         # a whole, under the kind "hsp_fftconv" (algorithmic flops and bytes of the direct form over all three launches)
         _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * 64 * 4 * Cc * Cc * Np,
                 4 * (64 * 2 * 2 * Cc * Np + 64 * 4 * Cc * Cc))
+        if before_inverse is not None:
+            torch.cuda.current_stream(x.device).wait_event(before_inverse)
         da.xf, da.xf_bs, da.dft = L.fptr(yf), yf.stride(0), L.fptr(finv)
         da.bias = L.fptr(self._b) if self._b is not None else None
         if res is not None:

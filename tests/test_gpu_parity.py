@@ -1632,3 +1632,50 @@ def test_denoise_end_to_end(device):
         denoise(torch.zeros(2, 800, device=device), mod, H.DENOISER_H)
     with pytest.raises(L.HspError):
         denoise(torch.zeros(800), mod, H.DENOISER_H)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,k,d,L,B", [(128, 11, 1, 1600, 2), (128, 11, 3, 800, 2), (128, 7, 5, 1000, 1), (128, 11, 1, 100, 3),
+                                        (128, 7, 1, 236, 2), (128, 11, 1, 40000, 1), (256, 7, 3, 4000, 2), (128, 11, 5, 33000, 1),
+                                        (512, 11, 1, 52, 2)])
+def test_frequency_domain_conv_with_its_activation_fused(C_, k, d, L, B, device):
+    """Conv1d.forward_fft(x, act1d=a): the anti-aliased SnakeBeta in front of an AMP conv applied while the forward
+    transform stages its input (hsp_dftseg_args.act_*) against the activation as its own launch followed by the same
+    conv (same arithmetic, so nearly bit for bit) and against the oracle's Activation1d + torch's float64 conv.  Row
+    ends inside a segment, rows shorter than a segment, several chunks per row, every dilation of the blocks."""
+    from oracle import hsp_oracle as O
+    from megatts2_hierspeechpp_amd import activations
+    from megatts2_hierspeechpp_amd.alias_free_torch import Activation1d
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    g = torch.Generator().manual_seed(7 * k + d + L)
+
+    class Pair(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.act = Activation1d(activation=activations.SnakeBeta(C_, alpha_logscale=True))
+            self.conv = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
+
+    m = Pair()
+    with torch.no_grad():
+        for p_ in m.conv.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g))
+        m.conv.weight_g.fill_(0.5)
+        m.act.act.alpha.copy_(0.3 * torch.randn(C_, generator=g))
+        m.act.act.beta.copy_(0.3 * torch.randn(C_, generator=g))
+    m.conv.enable_fft()
+    w = (m.conv.weight_g.data * m.conv.weight_v.data / m.conv.weight_v.data.flatten(1).norm(dim=1).view(-1, 1, 1)).double()
+    bias = m.conv.bias.data.clone().double()
+    alpha, beta = m.act.act.alpha.data.clone(), m.act.act.beta.data.clone()
+    finalize(m, device)
+    x = torch.randn(B, C_, L, generator=g)
+    res = torch.randn(B, C_, L, generator=g)
+    dx, dres = x.to(device), res.to(device)
+    fused = m.conv.forward_fft(dx, act1d=m.act, res=dres).cpu()
+    apart = m.conv.forward_fft(m.act(dx), res=dres).cpu()
+    assert float((fused - apart).abs().max()) <= 1e-6 * max(1.0, float(apart.abs().max())), "fused against separate activation"
+    h12 = O.kaiser_sinc_filter12()
+    ax = O.downsample2x(O.snake_beta(O.upsample2x(x, h12), alpha, beta), h12)   # Activation1d, alias_free_torch/act.py:23-28
+    ref = torch.nn.functional.conv1d(ax.double(), w, bias, dilation=d, padding=(k - 1) * d // 2) + res.double()
+    _close(fused.numpy(), ref.float().numpy(), f"act + fft conv C={C_} k={k} d={d} L={L}")
+
+
+
