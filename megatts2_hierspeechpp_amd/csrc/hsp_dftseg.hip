@@ -495,44 +495,73 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
   // the epilogue runs in the scalar form unless every row it touches is 16-B addressable (workgroup-uniform)
   const bool vec0 = ((a.L | (int)a.y_bs | (int)a.y_cs | (int)a.res_bs | (int)a.res_cs) & 3) == 0 &&
                     ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const DsItem I = ds_item(item, a, G);
-    const int S = I.S, ncols = I.ncg * d * S, nblk = (ncols + 31) >> 5;
+  // B operand of a column block: [E^ | O^][64 slots][32 columns], the same for all four waves, so it is staged through
+  // LDS once.  A thread fetches X[k] and X[64 - k] (bin 0's thread: DC | Nyquist and X[32]) of four bins of one column
+  // -- every load instruction two 128-B runs -- and stores E^ = X[k] + conj(X[64 - k]), O^ = (X[k] - conj(X[64 - k]))
+  // W^-k (the factor 1/2 is in the table).  The fetches run TWO column blocks ahead of the MFMAs, across item
+  // boundaries (the first block of the next row is in flight under this row's epilogue): a block is 32 MFMAs per wave,
+  // 1 us, less than one HBM round trip.
+  const int nmine = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto item_of = [&](int it) __attribute__((always_inline)) { return ds_item(blockIdx.x + it * gridDim.x, a, G); };
+  int it_f = 0, blk_f = 0;                                      // the position the next fetch reads
+  DsItem If = item_of(0);
+  int ncols_f = If.ncg * d * If.S;
+  bool more_f = true;
+  auto fetch_next = [&](float (&v)[16]) __attribute__((always_inline)) {
+    const DsCol q = ds_col(32 * blk_f + l32, ncols_f, d, If.S);
+    const float* src = a.xf + (int64_t)(If.c0 + q.ch) * a.Np + (If.b * d + q.p) * a.nseg + If.s0 + q.s;
+    const int64_t im = (int64_t)a.C * a.Np;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kf = 8 * wave + 4 * half + u, k2 = kf == 0 ? 32 : 64 - kf;
+      v[4 * u + 0] = src[(int64_t)kf * a.xf_bs];
+      v[4 * u + 1] = src[(int64_t)kf * a.xf_bs + im];
+      v[4 * u + 2] = src[(int64_t)k2 * a.xf_bs];
+      v[4 * u + 3] = src[(int64_t)k2 * a.xf_bs + im];
+    }
+    // advance (behind the last block of the last item the position stays: two harmless repeats)
+    if (32 * (blk_f + 1) < ncols_f) {
+      ++blk_f;
+    } else if (more_f && it_f + 1 < nmine) {
+      ++it_f;
+      blk_f = 0;
+      If = item_of(it_f);
+      ncols_f = If.ncg * d * If.S;
+    } else {
+      more_f = false;
+    }
+  };
+  auto stash = [&](int buf, const float (&v)[16]) __attribute__((always_inline)) {
+    float* dst = bbuf + buf * (128 * 32) + l32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kf = 8 * wave + 4 * half + u;
+      const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
+      const float dr = xr - yr, di = xi + yi;                   // X[k] - conj(X[64 - k])
+      const bool z = u == 0 && kf == 0;                         // (DC, Nyquist, Re X[32], Im X[32]): E^0 E^32 O^0 O^32 real
+      dst[kf * 32] = z ? xr + xi : xr + yr;                     // Re E^[k]
+      dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;            // Im E^[k]             (slot 32: E^[32] = 2 Re X[32])
+      dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];       // Re O^[k]
+      dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];    // Im O^[k]  (slot 32: O^[32] = -2 Im X[32])
+    }
+  };
+  // the position the MFMAs are at
+  int it_c = 0, blk_c = 0, buf = 0;
+  DsItem I = item_of(0);
+  int ncols = I.ncg * d * I.S;
+  bool done = false;
+  // One step = one column block: stage its operand (fetched two steps ago), refill the same registers with the block
+  // two steps ahead, multiply, scatter; behind the last block of an item, its epilogue.  Called alternately with the
+  // two register sets, so no set is ever copied (a copy would wait for the loads it copies).
+  auto step = [&](float (&v)[16]) __attribute__((always_inline)) {
+    const int S = I.S, nblk = (ncols + 31) >> 5;
     const int tb = d * I.s0 * hop;                              // output index of row[0]
     const int tl = min(a.L - tb, d * S * hop);                  // outputs of this chunk
-    if (item != (int)blockIdx.x) ds_barrier();                  // the previous item's outputs have left the stretch
-    // B operand of a column block: [E^ | O^][64 slots][32 columns], the same for all four waves, so it is staged through
-    // LDS once.  A thread fetches X[k] and X[64 - k] (bin 0's thread: DC | Nyquist and X[32]) of four bins of one column
-    // -- every load instruction two 128-B runs -- and stores E^ = X[k] + conj(X[64 - k]), O^ = (X[k] - conj(X[64 - k]))
-    // W^-k (the factor 1/2 is in the table).
-    auto fetch = [&](int cb, float (&v)[16]) __attribute__((always_inline)) {
-      const DsCol q = ds_col(cb + l32, ncols, d, S);
-      const float* src = a.xf + (int64_t)(I.c0 + q.ch) * a.Np + (I.b * d + q.p) * a.nseg + I.s0 + q.s;
-      const int64_t im = (int64_t)a.C * a.Np;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kf = 8 * wave + 4 * half + u, k2 = kf == 0 ? 32 : 64 - kf;
-        v[4 * u + 0] = src[(int64_t)kf * a.xf_bs];
-        v[4 * u + 1] = src[(int64_t)kf * a.xf_bs + im];
-        v[4 * u + 2] = src[(int64_t)k2 * a.xf_bs];
-        v[4 * u + 3] = src[(int64_t)k2 * a.xf_bs + im];
-      }
-    };
-    auto stash = [&](int buf, const float (&v)[16]) __attribute__((always_inline)) {
-      float* dst = bbuf + buf * (128 * 32) + l32;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kf = 8 * wave + 4 * half + u;
-        const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
-        const float dr = xr - yr, di = xi + yi;                 // X[k] - conj(X[64 - k])
-        const bool z = u == 0 && kf == 0;                       // (DC, Nyquist, Re X[32], Im X[32]): E^0 E^32 O^0 O^32 real
-        dst[kf * 32] = z ? xr + xi : xr + yr;                   // Re E^[k]
-        dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;          // Im E^[k]             (slot 32: E^[32] = 2 Re X[32])
-        dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];       // Re O^[k]
-        dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];    // Im O^[k]  (slot 32: O^[32] = -2 Im X[32])
-      }
-    };
-    auto consume = [&](int cb, int buf) __attribute__((always_inline)) {
+    // (the barrier behind the first stash of an item also says: everyone has left the previous item's epilogue)
+    stash(buf, v);
+    ds_barrier();
+    fetch_next(v);                                              // in flight under this block's and the next one's MFMAs
+    {
       const float* bp = bbuf + buf * (128 * 32) + eo * (64 * 32) + half * 32 + l32;
       ds_f32x16 acc, acc2;                                      // two chains: even / odd k-steps
 #pragma unroll
@@ -542,7 +571,7 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * 64], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks + 1], bp[ks * 64 + 64], acc2, 0, 0, 0);
       }
-      const DsCol q = ds_col(cb + l32, ncols, d, S);
+      const DsCol q = ds_col(32 * blk_c + l32, ncols, d, S);
       if (q.ok) {
         float* row = lds + q.ch * pitch;
 #pragma unroll
@@ -552,23 +581,32 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
           if (i < hop && j < tl) row[j] = acc[r] + acc2[r];
         }
       }
-    };
-    float v[16];
-    fetch(0, v);
-    stash(0, v);
-    ds_barrier();
-    int buf = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
-      const bool more = blk + 1 < nblk;                         // workgroup-uniform
-      if (more) fetch(32 * blk + 32, v);                        // in flight under this block's MFMAs
-      consume(32 * blk, buf);
-      if (nbuf == 1) ds_barrier();                              // one buffer: everyone has read it
-      if (more) stash(nbuf == 1 ? 0 : buf ^ 1, v);
-      ds_barrier();                                             // the next block is staged, the last one scattered
-      buf = nbuf == 1 ? 0 : buf ^ 1;
+    }
+    const bool last = blk_c + 1 == nblk;
+    if (nbuf == 1 || last) ds_barrier();                        // the buffer is free again / the item is scattered
+    buf = nbuf == 1 ? 0 : buf ^ 1;
+    if (!last) {
+      ++blk_c;
+      return;
     }
     if (vec0 && ((tb | tl) & 3) == 0) ds_inv_epilogue<4>(a, G, I, lds, 0, 1, tid, DS_MEM, tb, tl);
     else ds_inv_epilogue<1>(a, G, I, lds, 0, 1, tid, DS_MEM, tb, tl);
+    if (++it_c < nmine) {
+      blk_c = 0;
+      I = item_of(it_c);
+      ncols = I.ncg * d * I.S;
+    } else {
+      done = true;
+    }
+  };
+  float v1[16], v2[16];
+  fetch_next(v1);
+  fetch_next(v2);
+  while (true) {
+    step(v1);
+    if (done) break;
+    step(v2);
+    if (done) break;
   }
 }
 
