@@ -130,19 +130,30 @@ __device__ __forceinline__ DsStage ds_stage_of(const hsp_dftseg_args& a, const D
   s.tot = I.ncg * s.ng;
   return s;
 }
+// e / ng for 0 <= e < 2^22 (a per-lane integer division is ~25 VALU instructions, and the staging has 32 of them per
+// item): the float quotient is off by at most one
+__device__ __forceinline__ int ds_div(int e, int ng, float inv_ng) {
+  int q = (int)((float)e * inv_ng);
+  const int r = e - q * ng;
+  q += r >= ng ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
 __device__ __forceinline__ void ds_stage_load(const hsp_dftseg_args& a, const DsItem& I, const DsStage& s, int e0, int t,
                                               ds_f32x4 (&v)[16]) {
   const float* xb = a.x + (int64_t)I.b * a.x_bs + (int64_t)I.c0 * a.x_cs;
+  const float inv_ng = 1.0f / (float)s.ng;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
-    const int e = min(e0 + t + DS_MEM * u, s.tot - 1), ch = e / s.ng, gi = e - ch * s.ng;
+    const int e = min(e0 + t + DS_MEM * u, s.tot - 1), ch = I.ncg == 1 ? 0 : ds_div(e, s.ng, inv_ng), gi = e - ch * s.ng;
     v[u] = *reinterpret_cast<const ds_f32x4*>(xb + (int64_t)ch * a.x_cs + 4 * (s.g_lo + gi));
   }
 }
 __device__ __forceinline__ void ds_stage_write(const DsGeom& G, const DsStage& s, int e0, int t, float* buf, const ds_f32x4 (&v)[16]) {
+  const float inv_ng = 1.0f / (float)s.ng;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
-    const int e = e0 + t + DS_MEM * u, ch = min(e, s.tot - 1) / s.ng, gi = e - ch * s.ng;
+    const int e = e0 + t + DS_MEM * u, ch = s.tot == s.ng ? 0 : ds_div(min(e, s.tot - 1), s.ng, inv_ng), gi = e - ch * s.ng;
     // a group may hang over either end of the stretch by up to three samples: the rows have that slack
     if (e < s.tot) *reinterpret_cast<ds_f32x4*>(buf + ch * G.pitch + s.sh - s.t0 + 4 * (s.g_lo + gi)) = v[u];
   }

@@ -168,20 +168,20 @@ class AMPBlock1(nn.Module):
         return x
 
 
-# Where the frequency-domain form of an AMP conv beats the direct MFMA conv (tools/fftconv_bench.py, B = 32, same box;
-# profiles/r04_fftconv_bench.txt): k = 11 from 128 channels (1.39 x at 128, 1.8 x at 256, 1.5-2.1 x at 512 channels),
-# k = 7 at 256 channels (1.14-1.22 x) and at 512 channels up to dilation 3 (1.33 / 1.08 x; 0.95 x at dilation 5, where
-# L = 800 leaves two segments per phase half empty).  The channel product shrinks 5.0 x (k = 11) / 3.3 x (k = 7); what
-# the two transforms cost grows with the tensor, not with C^2, so the gain rises with the channel count -- 64 channels
-# lose (0.8 x / 0.5 x).  HSP_FFT_CONV=0 switches the form off (A/B runs, parity tests of both forms).
+# Where the frequency-domain form of an AMP conv beats the direct MFMA conv: fft_eligible (by shape) and fft_min_cols (by
+# samples per channel) below, both from tables measured on one box (tools/fftconv_bench.py; profiles/r04_fftconv_bench.txt,
+# r04_fftconv_batch.txt).  The channel product shrinks 5.0 x (k = 11) / 3.3 x (k = 7); what the two transforms cost grows
+# with the tensor, not with C^2, so the gain rises with the channel count.  HSP_FFT_CONV=0 switches the form off (A/B
+# runs, parity tests of both forms).
 FFT_CONV = os.environ.get("HSP_FFT_CONV", "1") == "1"
 
 
 def fft_eligible(channels: int, k: int, dilation: int) -> bool:
-    """Where the frequency-domain form wins at the Generator's shapes (profiles/r04_fftconv_bench.txt, 32 x 4 s)."""
-    if k >= 11:
-        return channels >= 128 or (channels >= 64 and dilation <= 3)
-    return k >= 7 and (channels >= 256 or (channels >= 128 and dilation <= 3))
+    """Where the frequency-domain form wins at the Generator's shapes (profiles/r04_fftconv_bench.txt, 32 x 4 s): k = 11
+    from 64 channels (1.05-1.18 x there, 1.7-2.5 x from 128), k = 7 from 128 (1.09-1.21 x; 1.2-1.6 x from 256); k = 3
+    never (0.4-0.8 x) and k = 7 at 64 channels not (0.7-0.8 x)."""
+    del dilation  # (every dilation of the blocks wins where dilation 1 does)
+    return channels >= 64 if k >= 11 else (k >= 7 and channels >= 128)
 
 
 def fft_min_cols(channels: int, k: int) -> int:
