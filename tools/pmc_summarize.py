@@ -3,7 +3,7 @@
 bench.py quotes `roofline.traffic` from that file ONLY when the kernel-source hash, the workload size and the launch mix
 recorded here equal the run's own (the library is identified by the hash of its kernel sources).
 
-    python tools/pmc_summarize.py gpurun_out profiles/r04_traffic.json
+    python tools/pmc_summarize.py gpurun_out profiles/r04_traffic.json [bench line of the same build]
 
 FETCH_SIZE on gfx950 under-reports wide coalesced reads (exactly 1/2 for 16-B-per-lane streams, MI355X_MICROARCH.md);
 three figures are given for every kernel class: raw (as counted), x2 (the guide's literal correction) and calibrated
@@ -17,7 +17,8 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = ["conv1d_mfma_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "act1d_seg_kernel", "act1d_kernel",
+CLASSES = ["conv1d_mfma_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "dftseg_fwd_kernel", "dftseg_inv_kernel",
+           "act1d_seg_kernel", "act1d_kernel",
            "mha_mfma_kernel", "mha_tok_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel"]
 B, T = 32, 200
 STEPS = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
@@ -43,14 +44,18 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             k["launches"] += 1
 
 # algorithmic bytes of the stand-alone activation launches of one vocoder step (one read, one write per element): the
-# 91 Activation1d of the Generator + 37 of the SourceNetwork at their (C, L) -- bench.py's ACT_HOOK sums the same figure
+# Activation1d launches that are NOT applied by a forward transform (hsp_dftseg_args.act_*).  Their count and bytes are
+# what bench.py's ACT_HOOK summed in the per-launch pass of the SAME build (`roofline_activation` of the line written by
+# tools/profile_final.sh, or any bench line given as third argument); the counter rows must show the same launch count.
+bench_line = sys.argv[3] if len(sys.argv) > 3 else os.path.join(src, "prof_final_bench.json")
+ra = json.loads(open(bench_line).read().strip().splitlines()[-1])["roofline_activation"]
 act = out["act1d_seg_kernel"]
-stage = [(512, 800), (256, 4000), (128, 16000), (64, 32000), (32, 64000)]
-act_elems = sum(18 * c * l for c, l in stage) + 32 * 64000           # generator: 18 per stage + activation_post
-act_elems += 18 * (256 * 400 + 128 * 800) + 128 * 800                # source network stages (256, 400), (128, 800) + post
-act_read_bytes = 4.0 * B * act_elems * STEPS
+n_act = ra["launches_per_step"]
+assert act["launches"] == n_act * STEPS, (act["launches"], n_act, "the launch mix is not the one the bench line prices")
+act_elems_bytes = ra["algorithmic_mb_per_step"] * 1e6 / 2          # read bytes per step (the hook books read + write)
+act_read_bytes = act_elems_bytes * STEPS
 fetch_factor = act_read_bytes / (act["FETCH_SIZE_KB"] * 1024)
-write_check = (4.0 * B * act_elems * STEPS) / (act["WRITE_SIZE_KB"] * 1024)
+write_check = act_read_bytes / (act["WRITE_SIZE_KB"] * 1024)
 
 
 def three(k):
@@ -74,7 +79,7 @@ res = {
     "conv1d_mfma_bytes_per_step": three(conv),
     "act1d_seg_bytes_per_step": three(act),
 }
-for name in ("rgemm_kernel", "bgemm_kernel", "mha_proj_kernel"):
+for name in ("rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "dftseg_fwd_kernel", "dftseg_inv_kernel"):
     if name in out:
         res[name + "_bytes_per_step"] = three(out[name])
 json.dump(res, open(dst, "w"), indent=1)
