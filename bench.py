@@ -278,8 +278,8 @@ def vocoder_roofline(args, wl, result):
             tiles[len(rec)] = f"{plan[0]}x{plan[1]}"
             kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else (
                 "hsp_conv1d_mfma_f32/rgemm" if plan[2] == -1 else "hsp_conv1d_mfma_f32/bgemm")
-        rec.append((kind, fl, nb, e0, e1, (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows) if la is not None
-                    else (0, 0, 0, 0, 0, 0, 0)))
+        rec.append((kind, fl, nb, e0, e1, la if isinstance(la, int) else
+                    (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows) if la is not None else (0, 0, 0, 0, 0, 0, 0)))
 
     Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
     hip_layers.LAUNCH_HOOK = hook
@@ -296,7 +296,7 @@ def vocoder_roofline(args, wl, result):
     if args.dump_launches:
         agg = {}
         for kind, fl, nb, e0, e1, shp in rec:
-            k = (kind,) + shp
+            k = (kind,) + (shp if isinstance(shp, tuple) else (0, 0, 0, 0, 0, 0, 0))
             n, f, m = agg.get(k, (0, 0, 0.0))
             agg[k] = (n + 1, f + fl, m + e0.elapsed_time(e1))
         with open(args.dump_launches, "w") as fh:
@@ -376,16 +376,18 @@ def vocoder_roofline(args, wl, result):
     # the flops they EXECUTE; here the convs they stand for: the direct form's algorithmic flops over the time of all
     # three launches -- the rate the direct kernel would have to reach to tie (its peak is 157.3).
     fc = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_fftconv"]
+    n_fc = sum((la if isinstance(la, int) else 1) for kind, fl, nb, e0, e1, la in rec if kind == "hsp_fftconv")   # a fused pair is one record
     if fc:
         tr = [(kind, fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind.startswith("hsp_dftseg")]
         f_ms, f_fl = sum(m for _, _, m in fc), sum(f for f, _, _ in fc)
         result["roofline"]["frequency_domain_convs"] = {
-            "convs_per_step": len(fc), "ms_per_step_all_three_launches": f_ms, "algorithmic_gflop_per_step": f_fl / 1e9,
+            "convs_per_step": n_fc, "ms_per_step_all_three_launches": f_ms, "algorithmic_gflop_per_step": f_fl / 1e9,
             "algorithmic_tflops": f_fl / (f_ms * 1e-3) / 1e12,
             "transform_launches_per_step": len(tr), "transform_ms_per_step": sum(m for _, _, m in tr),
             "transform_executed_tflops": sum(f for _, f, _ in tr) / (sum(m for _, _, m in tr) * 1e-3) / 1e12,
             "note": "algorithmic flops of the direct convs (2 k C^2 per output) over the time of forward DFT + channel product + "
-                    "inverse DFT; the product launches are also in `roofline` with their executed flops"}
+                    "inverse DFT (an AMP pair: forward, product, inverse + activation + forward in one launch, product, "
+                    "inverse); the product launches are also in `roofline` with their executed flops"}
     if act_rec:
         # second kernel of the step by time: the stand-alone anti-aliased activation, HBM-bound by design
         a_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in act_rec)

@@ -484,6 +484,14 @@ typedef struct hsp_dftseg_args {
 int hsp_dftseg_fwd_f32(const hsp_dftseg_args* a, void* stream);
 int hsp_dftseg_inv_f32(const hsp_dftseg_args* a, void* stream);
 int hsp_dftseg_tables_f32(float* fwd, float* inv); /* host buffers of HSP_DFTSEG_TABLE_FLOATS floats each */
+/* The two convs of an AMP pair (hierspeechpp_speechsynthesizer.py:380-384: xt = c1(a1(x)); xt = c2(a2(xt))) met in ONE
+ * launch: `inv` describes the inverse transform of c1's product (xf = c1's product output, dft = the inverse table, bias;
+ * no residual / running sum / post_scale), `fwd` the forward transform of c2's input (xf = c2's spectrum to write, dft =
+ * the forward table, act_* = a2, required); same B, C, L.  y of `inv` and x of `fwd` are not read: the tensor between
+ * the convs exists in LDS only.  hsp_dftseg_pair_supported: 1 if the pair fits (both unchunked, two row stretches in one
+ * CU's LDS), else 0 and the caller runs hsp_dftseg_inv_f32 + hsp_dftseg_fwd_f32. */
+int hsp_dftseg_pair_supported(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd);
+int hsp_dftseg_pair_f32(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd, void* stream);
 
 /* ------------------------------------------------ SURVEY.md §8(b) names (dispatching entry points) */
 /* The minimum export set of SURVEY.md §8(b) under its own names; each forwards to the entry points above.

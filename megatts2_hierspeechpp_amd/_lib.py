@@ -111,6 +111,8 @@ SIGNATURES = {
     "hsp_dftseg_fwd_f32": (C.c_int, [C.POINTER(DftSegArgs), _fp]),
     "hsp_dftseg_inv_f32": (C.c_int, [C.POINTER(DftSegArgs), _fp]),
     "hsp_dftseg_tables_f32": (C.c_int, [_fp, _fp]),
+    "hsp_dftseg_pair_supported": (C.c_int, [C.POINTER(DftSegArgs), C.POINTER(DftSegArgs)]),
+    "hsp_dftseg_pair_f32": (C.c_int, [C.POINTER(DftSegArgs), C.POINTER(DftSegArgs), _fp]),
     "hsp_mha_proj_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hsp_masked_mean_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_mask_mul_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),

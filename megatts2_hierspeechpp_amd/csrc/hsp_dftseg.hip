@@ -621,6 +621,214 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
   }
 }
 
+// ------------------------------------------------------------------------------- inverse -> activation -> forward
+// The two convs of an AMP pair (hierspeechpp_speechsynthesizer.py:380-384: xt = c1(a1(x)); xt = c2(a2(xt)); x = xt + x)
+// in their frequency-domain forms meet here: the inverse transform of c1's product, c1's bias, the activation a2 and the
+// forward transform of c2's input in ONE launch -- xt is never in HBM (a write and a read of the tensor, the staging
+// of the forward kernel and the epilogue of the inverse one go away).  One persistent 8-wave workgroup per CU, an item =
+// `cg` whole channel rows of one utterance (both convs unchunked), three phases separated by workgroup barriers:
+//   1. inverse of c1 into stretch A: the waves form two groups of four, each group one column block per step (fetches
+//      two steps ahead, across items, as in dftseg_inv_kernel);
+//   2. activation A -> stretch B (the forward stretch of c2: zero padding, 16-B shift): a wave per 240-sample segment,
+//      its raw window a 16-B LDS load of A instead of a global one, then exactly da_segment;
+//   3. forward of c2 out of B: four wave pairs on alternate column blocks.
+// LDS: A | B | (two 16-KB operand buffers of phase 1 = the eight activation slices of phase 2) | twiddles, taps.
+struct DpGeom {
+  int cg, ngrp, S1, pitchA, S2, pitchB, offB, offX, offT;
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dftseg_pair_kernel(
+    const hsp_dftseg_args ai, const hsp_dftseg_args af, const DpGeom G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  const int hop1 = DS_N - (ai.k - 1), d1 = ai.dil, hop2 = DS_N - (af.k - 1), d2 = af.dil;
+  float* const sA = lds;
+  float* const sB = lds + G.offB;
+  float* const twl = lds + G.offT;                              // forward twiddles (cos | sin)(2 pi k / 128)
+  float* const flt = twl + 64;                                  // activation taps as da_segment wants them
+  // phase-1 role: group grp of four waves, wave (eo, wh) of it; phase-3 role: pair pw, bin half wh3
+  const int grp = wave >> 2, w4 = wave & 3, wh1 = w4 & 1, eo = w4 >> 1;
+  const int pw = wave >> 1, wh3 = wave & 1;
+  float* const bbuf = lds + G.offX + grp * (128 * 32);
+  float* const slice = lds + G.offX + wave * DA_SLICE;
+  float fa1[32], fa3[32], twc[4], tws[4];
+  {
+    const float* frow = ai.dft + (32 * wh1 + l32) * DS_H + half;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) fa1[ks] = frow[2 * ks];
+    const float* grow = af.dft + (32 * wh3 + l32) * DS_H + half;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) fa3[ks] = grow[2 * ks];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      twc[u] = ai.dft[DS_H * DS_H + 8 * w4 + 4 * half + u];
+      tws[u] = ai.dft[DS_H * DS_H + 32 + 8 * w4 + 4 * half + u];
+    }
+  }
+  if (tid < 64) twl[tid] = af.dft[DS_H * DS_H + tid];
+  if (tid >= 64 && tid < 88) {
+    const int j = tid - 64, i = j >> 1;
+    flt[j] = j < 12 ? 2.0f * af.act_filt[10 - 2 * i + (j & 1)] : af.act_filt[j];
+  }
+  const int nitems = ai.B * G.ngrp;
+  const int nmine = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto item_of = [&](int it) __attribute__((always_inline)) {
+    DsItem I;
+    const int id = blockIdx.x + it * gridDim.x;
+    I.b = id / G.ngrp;
+    I.c0 = (id - I.b * G.ngrp) * G.cg;
+    I.ncg = min(G.cg, ai.C - I.c0);
+    I.s0 = 0;
+    I.S = G.S1;
+    return I;
+  };
+  // ---- phase-1 fetch stream of this group: blocks grp, grp + 2, ... of every item (a block behind the item's last one
+  // has no valid column: clamped addresses, nothing scattered), two steps ahead
+  int it_f = 0, st_f = 0;
+  DsItem If = item_of(0);
+  int ncols_f = If.ncg * d1 * G.S1;
+  bool more_f = true;
+  auto fetch_next = [&](float (&v)[16]) __attribute__((always_inline)) {
+    const DsCol q = ds_col(32 * (2 * st_f + grp) + l32, ncols_f, d1, G.S1);
+    const float* src = ai.xf + (int64_t)(If.c0 + q.ch) * ai.Np + (If.b * d1 + q.p) * ai.nseg + q.s;
+    const int64_t im = (int64_t)ai.C * ai.Np;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kf = 8 * w4 + 4 * half + u, k2 = kf == 0 ? 32 : 64 - kf;
+      v[4 * u + 0] = src[(int64_t)kf * ai.xf_bs];
+      v[4 * u + 1] = src[(int64_t)kf * ai.xf_bs + im];
+      v[4 * u + 2] = src[(int64_t)k2 * ai.xf_bs];
+      v[4 * u + 3] = src[(int64_t)k2 * ai.xf_bs + im];
+    }
+    if (64 * (st_f + 1) < ncols_f) {
+      ++st_f;
+    } else if (more_f && it_f + 1 < nmine) {
+      ++it_f;
+      st_f = 0;
+      If = item_of(it_f);
+      ncols_f = If.ncg * d1 * G.S1;
+    } else {
+      more_f = false;
+    }
+  };
+  auto stash = [&](const float (&v)[16]) __attribute__((always_inline)) {
+    float* dst = bbuf + l32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kf = 8 * w4 + 4 * half + u;
+      const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
+      const float dr = xr - yr, di = xi + yi;
+      const bool z = u == 0 && kf == 0;
+      dst[kf * 32] = z ? xr + xi : xr + yr;
+      dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;
+      dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];
+      dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];
+    }
+  };
+  const DsGeom Gf = {G.cg, G.S2, G.pitchB, G.ngrp, 1, 0};        // what da_segment reads of the forward geometry: pitch
+  float v1[16], v2[16];
+  fetch_next(v1);
+  fetch_next(v2);
+  __syncthreads();                                              // tables in LDS
+  bool odd = false;                                             // which register set the next step stages
+  for (int it = 0; it < nmine; ++it) {
+    const DsItem I = item_of(it);
+    const int ncols1 = I.ncg * d1 * G.S1, nst = (ncols1 + 63) >> 6;
+    // ---------------- phase 1
+    auto step1 = [&](float (&v)[16], int st) __attribute__((always_inline)) {
+      stash(v);
+      ds_barrier();
+      fetch_next(v);
+      const float* bp = bbuf + eo * (64 * 32) + half * 32 + l32;
+      ds_f32x16 acc, acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 32; ks += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[ks], bp[ks * 64], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[ks + 1], bp[ks * 64 + 64], acc2, 0, 0, 0);
+      }
+      const DsCol q = ds_col(32 * (2 * st + grp) + l32, ncols1, d1, G.S1);
+      if (q.ok) {
+        float* row = sA + q.ch * G.pitchA;
+        const float bz = ai.bias ? ai.bias[I.c0 + q.ch] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 2 * (32 * wh1 + DS_ACC_ROW(r, half)) + eo;
+          const int j = q.p + d1 * (q.s * hop1 + i);
+          if (i < hop1 && j < ai.L) row[j] = acc[r] + acc2[r] + bz;
+        }
+      }
+      ds_barrier();                                             // the operand buffer is free / A is complete
+    };
+    for (int st = 0; st < nst; ++st) {
+      if (odd) step1(v2, st);
+      else step1(v1, st);
+      odd = !odd;
+    }
+    // ---------------- phase 2: A -> act -> B
+    {
+      DsStage sg;
+      sg.t0 = -af.pad;
+      sg.len = d2 * ((G.S2 - 1) * hop2 + DS_N);
+      sg.sh = 4 + (sg.t0 & 3);
+      sg.g_lo = 0;
+      sg.ng = 0;
+      sg.tot = 0;
+      const DaItem da = da_item(af, I, sg);
+      for (int sI = wave; sI < da.nsegs; sI += 8) {
+        const int ch = sI / da.nsg, p0 = da.pa4 + DA_SEG * (sI - ch * da.nsg);
+        const ds_f32x4 rv = *reinterpret_cast<const ds_f32x4*>(sA + ch * G.pitchA + hsp_clampi(p0 - 8 + 4 * lane, 0, af.L - 4));
+        da_segment(af, Gf, I, sg, da, sI, lane, rv, slice, sB, flt);
+      }
+      for (int ch = 0; ch < I.ncg; ++ch) {                      // the conv's zero padding on either side
+        float* row = sB + ch * G.pitchB + sg.sh;
+        for (int j = tid; j < min(-sg.t0, sg.len); j += 512) row[j] = 0.0f;
+        for (int j = max(af.L - sg.t0, 0) + tid; j < sg.len; j += 512) row[j] = 0.0f;
+      }
+      ds_barrier();
+      // ---------------- phase 3: forward of c2 out of B
+      const int ncols2 = I.ncg * d2 * G.S2;
+      const float* buf = sB + sg.sh;
+      const int step = 4 * d2;
+      const unsigned rowb = 4u * (unsigned)af.xf_bs, imb = 4u * (unsigned)(af.C * af.Np);
+      const int lanek = 16 * wh3 + 4 * half;
+      for (int cb = 32 * pw; cb < ncols2; cb += 128) {
+        const DsCol q = ds_col(cb + l32, ncols2, d2, G.S2);
+        const float* bp = buf + q.ch * G.pitchB + q.p + d2 * (q.s * hop2 + 2 * half);
+        ds_f32x16 ae, ao;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ae[r] = ao[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+          ae = __builtin_amdgcn_mfma_f32_32x32x2f32(fa3[ks], bp[ks * step], ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f32_32x32x2f32(fa3[ks], bp[ks * step + d2], ao, 0, 0, 0);
+        }
+        if (q.ok) {
+          const unsigned colb = 4u * (unsigned)((I.c0 + q.ch) * af.Np + (I.b * d2 + q.p) * af.nseg + q.s);
+          char* const base = reinterpret_cast<char*>(af.xf);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int kr = (r & 3) + 8 * (r >> 2);
+            const float er = ae[r], ei = ae[r + 8], orr = ao[r], oi = ao[r + 8];
+            const float wc = twl[lanek + kr], ws = twl[32 + lanek + kr];
+            const float tr = wc * orr + ws * oi, ti = wc * oi - ws * orr;
+            const bool z = r == 0 && lanek == 0;
+            const unsigned o1 = colb + (unsigned)(lanek + kr) * rowb;
+            const unsigned o2 = colb + (z ? 32u : (unsigned)(64 - lanek - kr)) * rowb;
+            *reinterpret_cast<float*>(base + o1) = er + tr;
+            *reinterpret_cast<float*>(base + o1 + imb) = z ? er - tr : ei + ti;
+            *reinterpret_cast<float*>(base + o2) = z ? ei : er - tr;
+            *reinterpret_cast<float*>(base + o2 + imb) = z ? -oi : ti - ei;
+          }
+        }
+      }
+    }
+    // (the first barrier of the next item's phase 1 stands between these reads of B and anything that writes it)
+  }
+}
+
 int ds_check(const hsp_dftseg_args& a) {
   if (!a.xf || !a.dft || a.B <= 0 || a.C <= 0 || a.L <= 0 || a.k < 2 || a.k > 64 || a.dil < 1 || a.dil > 8) return HSP_EINVAL;
   const int hop = DS_N - (a.k - 1);
@@ -680,6 +888,31 @@ int64_t ds_resident(size_t lds_bytes) {
   }
   const int per = (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
   return (int64_t)cus * per;
+}
+
+// The pair kernel's geometry; cg == 0: the pair cannot be fused (the caller runs the two launches)
+DpGeom dp_geom(const hsp_dftseg_args& ai, const hsp_dftseg_args& af) {
+  DpGeom G = {};
+  if (ds_check(ai) || ds_check(af)) return G;
+  if (ai.B != af.B || ai.C != af.C || ai.L != af.L || ai.res || ai.accumulate || ai.post_scale != 1.0f) return G;
+  if (!af.act_alpha_exp || !af.act_beta_inv || !af.act_filt || (af.L & 3)) return G;
+  if (af.xf_bs * 64 * 4 > 0xffffffffll) return G;
+  const int hop1 = DS_N - (ai.k - 1), hop2 = DS_N - (af.k - 1);
+  G.S1 = ai.nseg;
+  G.S2 = af.nseg;
+  G.pitchA = (ai.dil * G.S1 * hop1 + 3) & ~3;
+  G.pitchB = (af.dil * ((G.S2 - 1) * hop2 + DS_N) + 12 + 3) & ~3;
+  const int avail = 160 * 1024 / 4 - 2 * 128 * 32 - 96;        // floats left for the two stretches
+  int cg = avail / (G.pitchA + G.pitchB);
+  cg = cg > 32 ? 32 : cg;
+  cg = cg > ai.C ? ai.C : cg;
+  if (cg < 1) return G;
+  G.cg = cg;
+  G.ngrp = (ai.C + cg - 1) / cg;
+  G.offB = cg * G.pitchA;
+  G.offX = G.offB + cg * G.pitchB;
+  G.offT = G.offX + 2 * 128 * 32;
+  return G;
 }
 }  // namespace
 
@@ -749,3 +982,23 @@ extern "C" int hsp_dftseg_inv_f32(const hsp_dftseg_args* ap, void* stream) {
                      nbuf);
   return (int)hipGetLastError();
 }
+
+extern "C" int hsp_dftseg_pair_supported(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd) {
+  return inv && fwd && dp_geom(*inv, *fwd).cg > 0 ? 1 : 0;
+}
+
+extern "C" int hsp_dftseg_pair_f32(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd, void* stream) {
+  if (!inv || !fwd) return HSP_EINVAL;
+  const DpGeom G = dp_geom(*inv, *fwd);
+  if (G.cg < 1) return HSP_EINVAL;
+  const size_t lds_bytes = (size_t)(G.offT + 96) * sizeof(float);
+  const int64_t items = (int64_t)inv->B * G.ngrp;
+  if (lds_bytes > 160 * 1024 || items > 0x7fffffff) return HSP_EINVAL;
+  const int64_t blocks = std::min<int64_t>(items, ds_resident(lds_bytes));
+  static hsp_lds_flags flags;
+  if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(dftseg_pair_kernel), 160 * 1024, flags)) return e;
+  hipLaunchKernelGGL(dftseg_pair_kernel, dim3((unsigned)blocks), dim3(512), lds_bytes, static_cast<hipStream_t>(stream), *inv,
+                     *fwd, G);
+  return (int)hipGetLastError();
+}
+

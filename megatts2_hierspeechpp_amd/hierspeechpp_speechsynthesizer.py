@@ -153,7 +153,11 @@ class AMPBlock1(nn.Module):
                 x = c2(xt, act1d=a2, **kw)
             else:
                 # a conv in its frequency-domain form applies its activation while the forward transform stages the
-                # input (hsp_dftseg_args.act_*): no launch, no act(x) in HBM
+                # input (hsp_dftseg_args.act_*): no launch, no act(x) in HBM; two such convs in a row also meet in one
+                # launch (inverse of c1 + a2 + forward of c2, hsp_dftseg_pair_f32): xt never in HBM either
+                if fft_wins(c1, x) and fft_wins(c2, x) and fft_act(x) and FFT_PAIR and c1.fft_pair_ok(c2, x):
+                    x = c1.forward_fft_pair(c2, x, act_first=a1, act_second=a2, before_inverse=before_last if last else None, **kw)
+                    continue
                 if fft_wins(c1, x):
                     xt = c1.forward_fft(x, act1d=a1) if fft_act(x) else c1.forward_fft(a1(x))
                 else:
@@ -199,6 +203,7 @@ def fft_wins(conv, x) -> bool:
 
 
 FFT_ACT = os.environ.get("HSP_FFT_ACT", "1") == "1"   # 0: the activation stays its own launch (A/B runs)
+FFT_PAIR = os.environ.get("HSP_FFT_PAIR", "1") == "1"  # 0: inverse and forward transform between the convs of a pair stay two launches
 
 
 def fft_act(x) -> bool:

@@ -424,6 +424,94 @@ class Conv1d(_ConvBase):
             if self._b is not None and not fused:
                 self._b.copy_(self._bias_src())
 
+    # The frequency-domain form in pieces (forward_fft strings them together; an AMP pair fuses the inverse of its first
+    # conv with the forward transform of its second: forward_fft_pair)
+    def _fft_args(self, B, Lx):
+        """hsp_dftseg_args of this conv for a [B, C, Lx] tensor: geometry only, no pointers."""
+        d, k = self.dilation, self.k
+        hop = 129 - k
+        nseg = -(-(-(-Lx // d)) // hop)
+        da = L.DftSegArgs()
+        da.B, da.C, da.L, da.k, da.dil, da.pad, da.nseg = B, self.cin, Lx, k, d, self.padding, nseg
+        da.Np = _round_up(B * d * nseg, 4)
+        da.post_scale = 1.0
+        return da
+
+    @staticmethod
+    def _fft_set_act(da, x_like, act1d):
+        if act1d._ea is None:
+            raise L.HspError("Activation1d used before finalize()")
+        da.act_alpha_exp, da.act_beta_inv, da.act_filt = L.fptr(act1d._ea), L.fptr(act1d._binv), L.fptr(act1d._filt)
+
+    def _fft_forward(self, x, act1d=None):
+        """x [B, C, L] -> spectrum [64][2 C][Np] (hsp_dftseg_fwd_f32), the activation applied on the way if given."""
+        B, Cc, Lx = x.shape
+        assert Cc == self.cin and x.stride(2) == 1 and self._wf is not None
+        da = self._fft_args(B, Lx)
+        xf = torch.empty(64, 2 * Cc, da.Np, dtype=torch.float32, device=x.device)
+        da.x, da.x_bs, da.x_cs = L.fptr(x), x.stride(0), x.stride(1)
+        da.xf, da.xf_bs, da.dft = L.fptr(xf), xf.stride(0), L.fptr(_dft_tables(x.device)[0])
+        if act1d is not None:
+            if not fft_act_fusable(x):
+                raise L.HspError("forward_fft(act1d=...) needs 16-B addressable rows")
+            self._fft_set_act(da, x, act1d)
+        hook, ev = LAUNCH_HOOK, None
+        if hook is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        L.check(L.lib().hsp_dftseg_fwd_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_fwd_f32")
+        if hook is not None:
+            ev[1].record()
+            hook("hsp_dftseg_fwd_f32", 2 * 2 * 64 * 64 * B * Cc * da.dil * da.nseg, 4 * (B * Cc * Lx + 128 * Cc * da.Np), ev[0], ev[1], None)
+        return xf, (ev[0] if ev else None)
+
+    def _fft_product(self, xf):
+        """ONE batched 1x1 launch over the 64 bins: yf[bin] = [[Wr, Wi], [-Wi, Wr]][bin] xf[bin]."""
+        Cc, Np = self.cin, xf.shape[2]
+        yf = torch.empty_like(xf)
+        a = L.Conv1dArgs()
+        a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xf), xf.stride(0), xf.stride(1), 1
+        a.B, a.Cin, a.Lin = 64, 2 * Cc, Np
+        a.w, a.K, a.dil, a.pad, a.stride = L.fptr(self._wf), 1, 1, 0, 1
+        a.M, a.w_ld, a.w_bs = 2 * Cc, 2 * Cc, 4 * Cc * Cc
+        a.zeros = L.fptr(_zeros(xf.device))
+        _set_out(a, yf, 64, 2 * Cc, Np)
+        a.ncols, a.rows, a.scale, a.post_scale = Np, L.ROWS_PLAIN, 1.0, 1.0
+        # the launches are booked with the flops / bytes they EXECUTE; the conv they stand for is reported once more, as
+        # a whole, under the kind "hsp_fftconv" (algorithmic flops and bytes of the direct form over all its launches)
+        _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * 64 * 4 * Cc * Cc * Np,
+                4 * (64 * 2 * 2 * Cc * Np + 64 * 4 * Cc * Cc))
+        return yf
+
+    def _fft_inverse_args(self, yf, B, Lx):
+        da = self._fft_args(B, Lx)
+        da.xf, da.xf_bs, da.dft = L.fptr(yf), yf.stride(0), L.fptr(_dft_tables(yf.device)[1])
+        da.bias = L.fptr(self._b) if self._b is not None else None
+        return da
+
+    def _fft_inverse(self, yf, B, Lx, *, res=None, out=None, accumulate=False, post_scale=1.0, before_inverse=None):
+        Cc = self.cin
+        if out is None:
+            out = torch.empty(B, Cc, Lx, dtype=torch.float32, device=yf.device)
+        assert out.shape == (B, Cc, Lx) and out.stride(2) == 1 and (res is None or (res.shape == out.shape and res.stride(2) == 1))
+        if before_inverse is not None:
+            torch.cuda.current_stream(yf.device).wait_event(before_inverse)
+        da = self._fft_inverse_args(yf, B, Lx)
+        da.y, da.y_bs, da.y_cs = L.fptr(out), out.stride(0), out.stride(1)
+        if res is not None:
+            da.res, da.res_bs, da.res_cs = L.fptr(res), res.stride(0), res.stride(1)
+        da.accumulate, da.post_scale = int(bool(accumulate)), float(post_scale)
+        hook, e1 = LAUNCH_HOOK, None
+        if hook is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(L.lib().hsp_dftseg_inv_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_inv_f32")
+        if hook is not None:
+            e1.record()
+            nio = 2 + bool(res is not None) + 2 * bool(accumulate)
+            hook("hsp_dftseg_inv_f32", 2 * 2 * 64 * 64 * B * Cc * da.dil * da.nseg, 4 * (B * Cc * Lx * (nio - 1) + 128 * Cc * da.Np), e0, e1, None)
+        return out, e1
+
     def forward_fft(self, x, *, res=None, out=None, accumulate=False, post_scale=1.0, act1d=None, before_inverse=None):
         """The conv in its frequency-domain form (enable_fft()): three launches -- forward DFT of 128-sample segments,
         ONE 1x1 product over the 64 bins on the conv kernel (hsp_conv1d_args.w_bs), inverse DFT with the conv's epilogue
@@ -433,66 +521,58 @@ class Conv1d(_ConvBase):
         that touches ``out``."""
         self._require_ready()
         B, Cc, Lx = x.shape
-        assert Cc == self.cin and x.stride(2) == 1 and self._wf is not None
-        d, k = self.dilation, self.k
-        hop = 129 - k
-        nseg = -(-(-(-Lx // d)) // hop)
-        Np = _round_up(B * d * nseg, 4)
-        f, finv = _dft_tables(x.device)
-        xf = torch.empty(64, 2 * Cc, Np, dtype=torch.float32, device=x.device)
-        yf = torch.empty(64, 2 * Cc, Np, dtype=torch.float32, device=x.device)
-        if out is None:
-            out = torch.empty(B, Cc, Lx, dtype=torch.float32, device=x.device)
-        assert out.shape == (B, Cc, Lx) and out.stride(2) == 1 and (res is None or (res.shape == out.shape and res.stride(2) == 1))
-        da = L.DftSegArgs()
-        da.x, da.x_bs, da.x_cs = L.fptr(x), x.stride(0), x.stride(1)
-        da.y, da.y_bs, da.y_cs = L.fptr(out), out.stride(0), out.stride(1)
-        da.B, da.C, da.L, da.k, da.dil, da.pad, da.nseg, da.Np = B, Cc, Lx, k, d, self.padding, nseg, Np
-        da.xf, da.xf_bs, da.dft = L.fptr(xf), xf.stride(0), L.fptr(f)
-        if act1d is not None:
-            if not fft_act_fusable(x):
-                raise L.HspError("forward_fft(act1d=...) needs 16-B addressable rows")
-            if act1d._ea is None:
-                raise L.HspError("Activation1d used before finalize()")
-            da.act_alpha_exp, da.act_beta_inv, da.act_filt = L.fptr(act1d._ea), L.fptr(act1d._binv), L.fptr(act1d._filt)
+        xf, e_first = self._fft_forward(x, act1d)
+        yf = self._fft_product(xf)
+        out, e_last = self._fft_inverse(yf, B, Lx, res=res, out=out, accumulate=accumulate, post_scale=post_scale,
+                                        before_inverse=before_inverse)
+        if LAUNCH_HOOK is not None:
+            nio = 2 + bool(res is not None) + 2 * bool(accumulate)
+            LAUNCH_HOOK("hsp_fftconv", 2 * B * Cc * Cc * self.k * Lx, 4 * B * Cc * Lx * nio + 4 * self.k * Cc * Cc, e_first, e_last, None)
+        return out
+
+    def fft_pair_ok(self, second, x) -> bool:
+        """Can the inverse transform of this conv be fused with the activation and the forward transform of ``second``
+        (hsp_dftseg_pair_f32) for an input like x?  Both unchunked and their two LDS stretches within one CU's 160 KB."""
+        if self._wf is None or second._wf is None or second.cin != self.cin or x.shape[2] % 4:
+            return False
+        B, _, Lx = x.shape
+        ia, fa = self._fft_args(B, Lx), second._fft_args(B, Lx)
+        dummy = L.fptr(_zeros(x.device))                          # the predicate reads geometry only; pointers must be non-null
+        ia.xf = ia.dft = fa.xf = fa.dft = fa.act_alpha_exp = fa.act_beta_inv = fa.act_filt = dummy
+        ia.xf_bs, fa.xf_bs = 2 * self.cin * ia.Np, 2 * self.cin * fa.Np
+        return bool(L.lib().hsp_dftseg_pair_supported(C.byref(ia), C.byref(fa)))
+
+    def forward_fft_pair(self, second, x, *, act_first, act_second, res=None, out=None, accumulate=False, post_scale=1.0,
+                         before_inverse=None):
+        """second(act_second(self(act_first(x)))) [+ res ...] with both convs in the frequency domain and the tensor between
+        them never in HBM: forward(x) -> product(self) -> [inverse + bias + act_second + forward] -> product(second) ->
+        inverse with second's epilogue.  Five launches instead of six (eight with the activations)."""
+        self._require_ready()
+        second._require_ready()
+        B, Cc, Lx = x.shape
+        xf, e_first = self._fft_forward(x, act_first)
+        yf = self._fft_product(xf)
+        ia = self._fft_inverse_args(yf, B, Lx)
+        fa = second._fft_args(B, Lx)
+        xf2 = torch.empty(64, 2 * Cc, fa.Np, dtype=torch.float32, device=x.device)
+        fa.xf, fa.xf_bs, fa.dft = L.fptr(xf2), xf2.stride(0), L.fptr(_dft_tables(x.device)[0])
+        self._fft_set_act(fa, x, act_second)
         hook = LAUNCH_HOOK
         if hook is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(L.lib().hsp_dftseg_fwd_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_fwd_f32")
-        da.act_alpha_exp = da.act_beta_inv = da.act_filt = None
+        L.check(L.lib().hsp_dftseg_pair_f32(C.byref(ia), C.byref(fa), L.stream_ptr()), "hsp_dftseg_pair_f32")
         if hook is not None:
             e1.record()
-            e_first = e0
-            hook("hsp_dftseg_fwd_f32", 2 * 2 * 64 * 64 * B * Cc * d * nseg, 4 * (B * Cc * Lx + 128 * Cc * Np), e0, e1, None)
-        a = L.Conv1dArgs()
-        a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xf), xf.stride(0), xf.stride(1), 1
-        a.B, a.Cin, a.Lin = 64, 2 * Cc, Np
-        a.w, a.K, a.dil, a.pad, a.stride = L.fptr(self._wf), 1, 1, 0, 1
-        a.M, a.w_ld, a.w_bs = 2 * Cc, 2 * Cc, 4 * Cc * Cc
-        a.zeros = L.fptr(_zeros(x.device))
-        _set_out(a, yf, 64, 2 * Cc, Np)
-        a.ncols, a.rows, a.scale, a.post_scale = Np, L.ROWS_PLAIN, 1.0, 1.0
-        # the launches are booked with the flops / bytes they EXECUTE; the conv they stand for is reported once more, as
-        # a whole, under the kind "hsp_fftconv" (algorithmic flops and bytes of the direct form over all three launches)
-        _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * 64 * 4 * Cc * Cc * Np,
-                4 * (64 * 2 * 2 * Cc * Np + 64 * 4 * Cc * Cc))
-        if before_inverse is not None:
-            torch.cuda.current_stream(x.device).wait_event(before_inverse)
-        da.xf, da.xf_bs, da.dft = L.fptr(yf), yf.stride(0), L.fptr(finv)
-        da.bias = L.fptr(self._b) if self._b is not None else None
-        if res is not None:
-            da.res, da.res_bs, da.res_cs = L.fptr(res), res.stride(0), res.stride(1)
-        da.accumulate, da.post_scale = int(bool(accumulate)), float(post_scale)
+            hook("hsp_dftseg_pair_f32", 2 * 2 * 64 * 64 * B * Cc * (ia.dil * ia.nseg + fa.dil * fa.nseg),
+                 4 * 128 * Cc * (ia.Np + fa.Np), e0, e1, None)
+        yf2 = second._fft_product(xf2)
+        out, e_last = second._fft_inverse(yf2, B, Lx, res=res, out=out, accumulate=accumulate, post_scale=post_scale,
+                                          before_inverse=before_inverse)
         if hook is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        L.check(L.lib().hsp_dftseg_inv_f32(C.byref(da), L.stream_ptr()), "hsp_dftseg_inv_f32")
-        if hook is not None:
-            e1.record()
             nio = 2 + bool(res is not None) + 2 * bool(accumulate)
-            hook("hsp_dftseg_inv_f32", 2 * 2 * 64 * 64 * B * Cc * d * nseg, 4 * (B * Cc * Lx * (nio - 1) + 128 * Cc * Np), e0, e1, None)
-            hook("hsp_fftconv", 2 * B * Cc * Cc * k * Lx, 4 * B * Cc * Lx * nio + 4 * k * Cc * Cc, e_first, e1, None)
+            hook("hsp_fftconv", 2 * B * Cc * Cc * (self.k + second.k) * Lx, 4 * B * Cc * Lx * nio + 4 * (self.k + second.k) * Cc * Cc,
+                 e_first, e_last, 2)   # (two convs)
         return out
 
     # ----------------------------------------------------------------------------

@@ -1677,5 +1677,59 @@ def test_frequency_domain_conv_with_its_activation_fused(C_, k, d, L, B, device)
     ref = torch.nn.functional.conv1d(ax.double(), w, bias, dilation=d, padding=(k - 1) * d // 2) + res.double()
     _close(fused.numpy(), ref.float().numpy(), f"act + fft conv C={C_} k={k} d={d} L={L}")
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,k,d,L,B", [(128, 11, 1, 1600, 2), (128, 11, 3, 800, 2), (128, 7, 5, 1000, 3), (128, 11, 1, 100, 2),
+                                        (128, 7, 1, 236, 2), (128, 11, 1, 16000, 1), (128, 7, 5, 16000, 1), (256, 7, 3, 4000, 2),
+                                        (512, 11, 5, 52, 2), (128, 11, 1, 33000, 1)])
+def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, device):
+    """Conv1d.forward_fft_pair: c2(a2(c1(a1(x)))) + res with the inverse transform of c1, c1's bias, a2 and the forward
+    transform of c2 in ONE launch (hsp_dftseg_pair_f32; the tensor between the convs only in LDS) against the same two
+    convs each through forward_fft (same arithmetic: nearly bit for bit) and against the oracle's Activation1d + torch's
+    float64 convs (hierspeechpp_speechsynthesizer.py:380-384).  The last case is too long for one LDS stretch: the
+    predicate must say so."""
+    from oracle import hsp_oracle as O
+    from megatts2_hierspeechpp_amd import activations
+    from megatts2_hierspeechpp_amd.alias_free_torch import Activation1d
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    g = torch.Generator().manual_seed(3 * k + d + L)
+
+    class Pair(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a1 = Activation1d(activation=activations.SnakeBeta(C_, alpha_logscale=True))
+            self.a2 = Activation1d(activation=activations.SnakeBeta(C_, alpha_logscale=True))
+            self.c1 = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
+            self.c2 = Conv1d(C_, C_, k, dilation=1, padding=(k - 1) // 2, weight_norm=True)
+
+    m = Pair()
+    with torch.no_grad():
+        for c in (m.c1, m.c2):
+            for p_ in c.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g))
+            c.weight_g.fill_(0.5)
+        for a in (m.a1, m.a2):
+            a.act.alpha.copy_(0.3 * torch.randn(C_, generator=g))
+            a.act.beta.copy_(0.3 * torch.randn(C_, generator=g))
+    m.c1.enable_fft()
+    m.c2.enable_fft()
+    wn = lambda c: (c.weight_g.data * c.weight_v.data / c.weight_v.data.flatten(1).norm(dim=1).view(-1, 1, 1)).double()
+    w1, w2, b1, b2 = wn(m.c1), wn(m.c2), m.c1.bias.data.clone().double(), m.c2.bias.data.clone().double()
+    al = [(a.act.alpha.data.clone(), a.act.beta.data.clone()) for a in (m.a1, m.a2)]
+    finalize(m, device)
+    x = torch.randn(B, C_, L, generator=g)
+    dx = x.to(device)
+    if L > 20000:
+        assert not m.c1.fft_pair_ok(m.c2, dx)
+        return
+    assert m.c1.fft_pair_ok(m.c2, dx)
+    fused = m.c1.forward_fft_pair(m.c2, dx, act_first=m.a1, act_second=m.a2, res=dx).cpu()
+    apart = m.c2.forward_fft(m.c1.forward_fft(dx, act1d=m.a1), act1d=m.a2, res=dx).cpu()
+    assert float((fused - apart).abs().max()) <= 2e-6 * max(1.0, float(apart.abs().max())), "one launch against two"
+    h12 = O.kaiser_sinc_filter12()
+    act = lambda t, ab: O.downsample2x(O.snake_beta(O.upsample2x(t, h12), ab[0], ab[1]), h12)
+    xt = torch.nn.functional.conv1d(act(x, al[0]).double(), w1, b1, dilation=d, padding=(k - 1) * d // 2).float()
+    ref = torch.nn.functional.conv1d(act(xt, al[1]).double(), w2, b2, padding=(k - 1) // 2) + x.double()
+    _close(fused.numpy(), ref.float().numpy(), f"AMP pair in the frequency domain C={C_} k={k} d={d} L={L}")
+
 
 
