@@ -41,6 +41,11 @@
 // MFMAs either).  Tried and measured slower in round 4: waves split by role (four MFMA + four memory waves per CU over
 // two LDS stretches: one MFMA wave per SIMD ran at half the MFMA rate and the transform stayed at ~2.9 TB/s), smaller
 // LDS budgets for more workgroups per CU, non-temporal loads / stores, an odd LDS lane stride (no bank-conflict gain).
+// The fused activation (below) was also tried with the three stages of consecutive 112-sample segments in one step (one
+// LDS round trip per step instead of three per segment): 40 % MORE VALU instructions per output (56-59 of 64 lanes busy,
+// per-step bookkeeping) and the forward launches went from 5.2 to 7.3 ms per step -- the phase is bound by VALU issue,
+// which the fp32 MFMA shares, not by LDS latency.  A start delay for the second workgroup of a CU (to put its
+// activation phase under the first one's MFMAs) changed nothing for the same reason.
 #include "hsp_device.h"
 #include <algorithm>
 #include <cmath>
