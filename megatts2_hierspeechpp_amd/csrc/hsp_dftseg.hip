@@ -196,7 +196,7 @@ __device__ __forceinline__ ds_f32x4 da_load(const hsp_dftseg_args& a, const DsIt
 // one segment: raw window in registers -> act -> the stretch (row[j + sh] = act(x)[t0 + j] for t0 + j in [pa, pb))
 __device__ __forceinline__ void da_segment(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const DsStage& s,
                                            const DaItem& A, int sI, int lane, ds_f32x4 rv, float* slice, float* buf,
-                                           const float* flt) {
+                                           const float* flt, float add = 0.0f) {
   const int ch = sI / A.nsg, p0 = A.pa4 + DA_SEG * (sI - ch * A.nsg);
   const int n_out = min(DA_SEG, a.L - p0);                      // a multiple of 4
   const int c = I.c0 + ch;
@@ -213,7 +213,7 @@ __device__ __forceinline__ void da_segment(const hsp_dftseg_args& a, const DsGeo
   // ---- phase A: registers -> LDS (replicate padding: the clamped address was 0 or L - 4)
   {
     const int idx = p0 - 8 + 4 * lane;
-    ds_f32x4 t = rv;
+    ds_f32x4 t = rv + add;                                      // (the pair kernel: the first conv's bias)
     t = idx < 0 ? ds_f32x4{t.x, t.x, t.x, t.x} : t;
     t = idx >= a.L ? ds_f32x4{t.w, t.w, t.w, t.w} : t;
     *reinterpret_cast<ds_f32x4*>(raw + 4 * lane) = t;
@@ -757,12 +757,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const DsCol q = ds_col(32 * (2 * st + grp) + l32, ncols1, d1, G.S1);
       if (q.ok) {
         float* row = sA + q.ch * G.pitchA;
-        const float bz = ai.bias ? ai.bias[I.c0 + q.ch] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = 2 * (32 * wh1 + DS_ACC_ROW(r, half)) + eo;
           const int j = q.p + d1 * (q.s * hop1 + i);
-          if (i < hop1 && j < ai.L) row[j] = acc[r] + acc2[r] + bz;
+          // (c1's bias joins in phase 2: a load in this branch would wait for the fetches just issued -- vmcnt(0))
+          if (i < hop1 && j < ai.L) row[j] = acc[r] + acc2[r];
         }
       }
       ds_barrier();                                             // the operand buffer is free / A is complete
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int sI = wave; sI < da.nsegs; sI += 8) {
         const int ch = sI / da.nsg, p0 = da.pa4 + DA_SEG * (sI - ch * da.nsg);
         const ds_f32x4 rv = *reinterpret_cast<const ds_f32x4*>(sA + ch * G.pitchA + hsp_clampi(p0 - 8 + 4 * lane, 0, af.L - 4));
-        da_segment(af, Gf, I, sg, da, sI, lane, rv, slice, sB, flt);
+        da_segment(af, Gf, I, sg, da, sI, lane, rv, slice, sB, flt, ai.bias ? ai.bias[I.c0 + ch] : 0.0f);
       }
       for (int ch = 0; ch < I.ncg; ++ch) {                      // the conv's zero padding on either side
         float* row = sB + ch * G.pitchB + sg.sh;
