@@ -279,7 +279,8 @@ def vocoder_roofline(args, wl, result):
             kind = "hsp_conv1d_mfma_f32" if plan[2] > 0 else (
                 "hsp_conv1d_mfma_f32/rgemm" if plan[2] == -1 else "hsp_conv1d_mfma_f32/bgemm")
         rec.append((kind, fl, nb, e0, e1, la if isinstance(la, int) else
-                    (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows) if la is not None else (0, 0, 0, 0, 0, 0, 0)))
+                    (la.Cin, la.Cout, la.K, la.dil, la.Lout, la.prologue, la.rows, int(bool(la.w_bs))) if la is not None
+                    else (0, 0, 0, 0, 0, 0, 0, 0)))
 
     Fh.ACT_HOOK = lambda nb, e0, e1: act_rec.append((nb, e0, e1))
     hip_layers.LAUNCH_HOOK = hook
@@ -296,7 +297,7 @@ def vocoder_roofline(args, wl, result):
     if args.dump_launches:
         agg = {}
         for kind, fl, nb, e0, e1, shp in rec:
-            k = (kind,) + (shp if isinstance(shp, tuple) else (0, 0, 0, 0, 0, 0, 0))
+            k = (kind,) + (shp[:7] if isinstance(shp, tuple) else (0, 0, 0, 0, 0, 0, 0))
             n, f, m = agg.get(k, (0, 0, 0.0))
             agg[k] = (n + 1, f + fl, m + e0.elapsed_time(e1))
         with open(args.dump_launches, "w") as fh:
@@ -371,6 +372,14 @@ def vocoder_roofline(args, wl, result):
         "frac": fl2 / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         "note": "conv1d_mfma_kernel launches with more than 200 output columns per utterance (Generator + SourceNetwork): "
                 "the population BENCH_r02's roofline.frac was computed over; a subset of `roofline`'s launches"}
+    # (round 4) the same population split by what the launch is: a conv of the path in its direct form, or the K = 1
+    # channel product of a frequency-domain conv (per-bin weights, hsp_conv1d_args.w_bs) -- a launch class round 3 did not have
+    for name, sel in (("direct_convs", 0), ("channel_products", 1)):
+        part = [(fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, shp in rec if kind == "hsp_conv1d_mfma_f32" and shp[7] == sel]
+        if part:
+            pms, pfl = sum(m for _, m in part), sum(f for f, _ in part)
+            result["roofline"][name] = {"launches_per_step": len(part), "kernel_ms_per_step": pms, "achieved": pfl / (pms * 1e-3) / 1e12,
+                                        "frac": pfl / (pms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
     # (round 4) the long AMP convs run in their frequency-domain form (forward DFT, ONE batched 1x1 product over the 64
     # bins on conv1d_mfma_kernel, inverse DFT: csrc/hsp_dftseg.hip).  `roofline` above counts the product launches with
     # the flops they EXECUTE; here the convs they stand for: the direct form's algorithmic flops over the time of all
