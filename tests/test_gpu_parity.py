@@ -1678,15 +1678,17 @@ def test_frequency_domain_conv_with_its_activation_fused(C_, k, d, L, B, device)
     _close(fused.numpy(), ref.float().numpy(), f"act + fft conv C={C_} k={k} d={d} L={L}")
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C_,k,d,L,B", [(128, 11, 1, 1600, 2), (128, 11, 3, 800, 2), (128, 7, 5, 1000, 3), (128, 11, 1, 100, 2),
-                                        (128, 7, 1, 236, 2), (128, 11, 1, 16000, 1), (128, 7, 5, 16000, 1), (256, 7, 3, 4000, 2),
-                                        (512, 11, 5, 52, 2), (128, 11, 1, 33000, 1)])
-def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, device):
+@pytest.mark.parametrize("C_,k,d,L,B,k2", [(128, 11, 1, 1600, 2, 11), (128, 11, 3, 800, 2, 11), (128, 7, 5, 1000, 3, 7),
+                                           (128, 11, 1, 100, 2, 11), (128, 7, 1, 236, 2, 7), (128, 11, 1, 16000, 1, 11),
+                                           (128, 7, 5, 16000, 1, 7), (256, 7, 3, 4000, 2, 7), (512, 11, 5, 52, 2, 11),
+                                           (128, 11, 1, 33000, 1, 11), (136, 11, 3, 1204, 2, 7), (128, 5, 2, 600, 2, 9)])
+def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, k2, device):
     """Conv1d.forward_fft_pair: c2(a2(c1(a1(x)))) + res with the inverse transform of c1, c1's bias, a2 and the forward
     transform of c2 in ONE launch (hsp_dftseg_pair_f32; the tensor between the convs only in LDS) against the same two
     convs each through forward_fft (same arithmetic: nearly bit for bit) and against the oracle's Activation1d + torch's
-    float64 convs (hierspeechpp_speechsynthesizer.py:380-384).  The last case is too long for one LDS stretch: the
-    predicate must say so."""
+    float64 convs (hierspeechpp_speechsynthesizer.py:380-384).  One case is too long for one LDS stretch (the predicate
+    must say so); the last two pair convs of different kernel sizes (the kernel takes each conv's own segment hop) on a
+    channel count that leaves a partial last row group."""
     from oracle import hsp_oracle as O
     from megatts2_hierspeechpp_amd import activations
     from megatts2_hierspeechpp_amd.alias_free_torch import Activation1d
@@ -1699,7 +1701,7 @@ def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, device):
             self.a1 = Activation1d(activation=activations.SnakeBeta(C_, alpha_logscale=True))
             self.a2 = Activation1d(activation=activations.SnakeBeta(C_, alpha_logscale=True))
             self.c1 = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
-            self.c2 = Conv1d(C_, C_, k, dilation=1, padding=(k - 1) // 2, weight_norm=True)
+            self.c2 = Conv1d(C_, C_, k2, dilation=1, padding=(k2 - 1) // 2, weight_norm=True)
 
     m = Pair()
     with torch.no_grad():
@@ -1728,8 +1730,8 @@ def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, device):
     h12 = O.kaiser_sinc_filter12()
     act = lambda t, ab: O.downsample2x(O.snake_beta(O.upsample2x(t, h12), ab[0], ab[1]), h12)
     xt = torch.nn.functional.conv1d(act(x, al[0]).double(), w1, b1, dilation=d, padding=(k - 1) * d // 2).float()
-    ref = torch.nn.functional.conv1d(act(xt, al[1]).double(), w2, b2, padding=(k - 1) // 2) + x.double()
-    _close(fused.numpy(), ref.float().numpy(), f"AMP pair in the frequency domain C={C_} k={k} d={d} L={L}")
+    ref = torch.nn.functional.conv1d(act(xt, al[1]).double(), w2, b2, padding=(k2 - 1) // 2) + x.double()
+    _close(fused.numpy(), ref.float().numpy(), f"AMP pair in the frequency domain C={C_} k={k} / {k2} d={d} L={L}")
 
 
 
