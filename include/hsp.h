@@ -480,6 +480,11 @@ typedef struct hsp_dftseg_args {
   const float* act_alpha_exp;
   const float* act_beta_inv;
   const float* act_filt;
+  /* forward (and the forward half of the pair launch): non-zero = the spectrum feeds hsp_cprod3_f32, whose three-product
+   * form cannot keep the two real bins of slot 0 apart by its matrices alone: slot 0 then holds (-E0, -O0) -- the 64-point
+   * transforms of the even / odd samples at bin 0 -- instead of (DC, Nyquist) = (E0 + O0, E0 - O0).  0 = the layout above
+   * (the [2C x 2C] block product on hsp_conv1d_mfma_f32). */
+  int32_t prod3;
 } hsp_dftseg_args;
 int hsp_dftseg_fwd_f32(const hsp_dftseg_args* a, void* stream);
 int hsp_dftseg_inv_f32(const hsp_dftseg_args* a, void* stream);
@@ -492,6 +497,44 @@ int hsp_dftseg_tables_f32(float* fwd, float* inv); /* host buffers of HSP_DFTSEG
  * CU's LDS), else 0 and the caller runs hsp_dftseg_inv_f32 + hsp_dftseg_fwd_f32. */
 int hsp_dftseg_pair_supported(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd);
 int hsp_dftseg_pair_f32(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd, void* stream);
+
+/* Is the frequency-domain form available for this geometry?  1 when hsp_dftseg_fwd_f32 / hsp_dftseg_inv_f32 accept the
+ * arguments' B, C, L, k, dil, pad, nseg, Np, xf_bs (pointers are not read): dilation <= 8, the spectrum of one launch
+ * below 4 GiB (the kernels address it with 32-bit byte offsets: xf_bs * 256 <= 0xffffffff), item counts within int, the
+ * LDS stretch of one row chunk within a CU's 160 KB.  0 = the caller keeps the direct conv (hsp_conv1d_mfma_f32), which
+ * has no such limit (hierspeechpp_speechsynthesizer.py:377-386,635-651: the reference has no batch or length limit). */
+int hsp_dftseg_supported(const hsp_dftseg_args* a);
+
+/* ------------------------------------------------ channel product in three real products per bin (round 5)
+ * yf[bin] = conj(rfft(w, 128))[bin] xf[bin] for every bin of a spectrum written by hsp_dftseg_fwd_f32 with prod3 = 1
+ * (csrc/hsp_cprod3.hip): with conj(W) = a + i b and X = Xr + i Xi (rows [0, C) / [C, 2C) of a bin's [2C][Np] matrix)
+ *     k1 = (a + b) Xr,  k2 = a (Xi - Xr),  k3 = b (Xr + Xi);   Yr = k1 - k3,  Yi = k1 + k2
+ * -- 6 C^2 instead of 8 C^2 flops per column and 3 C^2 instead of 4 C^2 weights per bin.  w: [bins][3][C][C], the matrices
+ * (a + b), a, b of every bin stored [input channel][output row] (hsp_dftseg_weight_spectrum_f32 writes them; bin 0:
+ * (0, W_nyquist, W_dc)).  C a multiple of 64, Np a multiple of 4, xf / w 16-B aligned, xf_bs / yf_bs multiples of 4;
+ * `zeros`: >= 16 B of zeros in device memory (the source of DMA lanes past Np).  Replaces the one launch of
+ * hsp_conv1d_mfma_f32 with w_bs != 0 between the two transforms (reference: the C x C channel mix of the k = 7 / 11
+ * convs of AMPBlock1, hierspeechpp_speechsynthesizer.py:349-364). */
+typedef struct hsp_cprod3_args {
+  const float* xf;
+  float* yf;
+  const float* w;
+  const float* zeros;
+  int64_t xf_bs, yf_bs; /* floats between bins, >= 2 C Np */
+  int32_t bins, C, Np;
+} hsp_cprod3_args;
+int hsp_cprod3_f32(const hsp_cprod3_args* a, void* stream);
+int hsp_cprod3_supported(const hsp_cprod3_args* a);
+/* The per-bin matrices of a conv from its packed taps w[k][C][w_ld] (hsp_conv1d_args.w of a C -> C conv, row m of input
+ * channel ci and tap j at w[(j * C + ci) * w_ld + m]), on the device: 128-point DFT of the k <= 64 taps of every (ci, m)
+ * pair in float64 with the twiddles of `tw` (256 doubles in device memory: cos(2 pi n / 128), n < 128, then sin),
+ * conjugated and rounded once to fp32.  form HSP_WSPEC_THREE: out [64][3][C][C] for hsp_cprod3_f32; HSP_WSPEC_BLOCK: out
+ * [64][2C][2C], the block matrices of the hsp_conv1d_mfma_f32 form (w_bs = 4 C^2).  Every rank of a multi-GPU job derives
+ * them from the broadcast taps (the broadcast carries the folded weights only). */
+#define HSP_WSPEC_BLOCK 0
+#define HSP_WSPEC_THREE 1
+int hsp_dftseg_weight_spectrum_f32(const float* w, int32_t k, int32_t C, int32_t w_ld, const double* tw, float* out,
+                                   int32_t form, void* stream);
 
 /* ------------------------------------------------ SURVEY.md §8(b) names (dispatching entry points) */
 /* The minimum export set of SURVEY.md §8(b) under its own names; each forwards to the entry points above.

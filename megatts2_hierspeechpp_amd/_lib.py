@@ -86,8 +86,19 @@ class DftSegArgs(C.Structure):
         ("xf", _fp), ("xf_bs", C.c_int64), ("dft", _fp),
         ("bias", _fp), ("res", _fp), ("res_bs", C.c_int64), ("res_cs", C.c_int64),
         ("accumulate", C.c_int32), ("post_scale", C.c_float),
-        ("act_alpha_exp", _fp), ("act_beta_inv", _fp), ("act_filt", _fp),
+        ("act_alpha_exp", _fp), ("act_beta_inv", _fp), ("act_filt", _fp), ("prod3", C.c_int32),
     ]
+
+
+class Cprod3Args(C.Structure):
+    """Mirror of ``hsp_cprod3_args``."""
+    _fields_ = [
+        ("xf", _fp), ("yf", _fp), ("w", _fp), ("zeros", _fp), ("xf_bs", C.c_int64), ("yf_bs", C.c_int64),
+        ("bins", C.c_int32), ("C", C.c_int32), ("Np", C.c_int32),
+    ]
+
+
+WSPEC_BLOCK, WSPEC_THREE = 0, 1
 
 
 # symbol -> (restype, argtypes); every symbol include/hsp.h declares
@@ -113,6 +124,10 @@ SIGNATURES = {
     "hsp_dftseg_tables_f32": (C.c_int, [_fp, _fp]),
     "hsp_dftseg_pair_supported": (C.c_int, [C.POINTER(DftSegArgs), C.POINTER(DftSegArgs)]),
     "hsp_dftseg_pair_f32": (C.c_int, [C.POINTER(DftSegArgs), C.POINTER(DftSegArgs), _fp]),
+    "hsp_dftseg_supported": (C.c_int, [C.POINTER(DftSegArgs)]),
+    "hsp_cprod3_f32": (C.c_int, [C.POINTER(Cprod3Args), _fp]),
+    "hsp_cprod3_supported": (C.c_int, [C.POINTER(Cprod3Args)]),
+    "hsp_dftseg_weight_spectrum_f32": (C.c_int, [_fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, _fp]),
     "hsp_mha_proj_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hsp_masked_mean_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "hsp_mask_mul_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp]),

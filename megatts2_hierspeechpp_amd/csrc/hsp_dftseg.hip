@@ -430,8 +430,9 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const float wc = twl[lanek + (r & 3) + 8 * (r >> 2)], ws = twl[32 + lanek + (r & 3) + 8 * (r >> 2)];
         const float tr = wc * orr + ws * oi, ti = wc * oi - ws * orr;
         const bool z = r == 0 && wh == 0 && half == 0;
-        ov[4 * r + 0] = er + tr;
-        ov[4 * r + 1] = z ? er - tr : ei + ti;
+        const bool z3 = z && a.prod3;                           // slot 0 for the three-product form: (-E0, -O0), hsp.h prod3
+        ov[4 * r + 0] = z3 ? -er : er + tr;
+        ov[4 * r + 1] = z ? (a.prod3 ? -tr : er - tr) : ei + ti;
         ov[4 * r + 2] = z ? ei : er - tr;
         ov[4 * r + 3] = z ? -oi : ti - ei;
       }
@@ -820,10 +821,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float wc = twl[lanek + kr], ws = twl[32 + lanek + kr];
             const float tr = wc * orr + ws * oi, ti = wc * oi - ws * orr;
             const bool z = r == 0 && lanek == 0;
+            const bool z3 = z && af.prod3;                      // (-E0, -O0) in slot 0: hsp.h prod3
             const unsigned o1 = colb + (unsigned)(lanek + kr) * rowb;
             const unsigned o2 = colb + (z ? 32u : (unsigned)(64 - lanek - kr)) * rowb;
-            *reinterpret_cast<float*>(base + o1) = er + tr;
-            *reinterpret_cast<float*>(base + o1 + imb) = z ? er - tr : ei + ti;
+            *reinterpret_cast<float*>(base + o1) = z3 ? -er : er + tr;
+            *reinterpret_cast<float*>(base + o1 + imb) = z ? (af.prod3 ? -tr : er - tr) : ei + ti;
             *reinterpret_cast<float*>(base + o2) = z ? ei : er - tr;
             *reinterpret_cast<float*>(base + o2 + imb) = z ? -oi : ti - ei;
           }
@@ -919,7 +921,26 @@ DpGeom dp_geom(const hsp_dftseg_args& ai, const hsp_dftseg_args& af) {
   G.offT = G.offX + 2 * 128 * 32;
   return G;
 }
+// what hsp_dftseg_fwd_f32 / hsp_dftseg_inv_f32 refuse beyond ds_check, from the geometry alone (hsp_dftseg_supported)
+int ds_limits(const hsp_dftseg_args& a, bool act) {
+  if (a.xf_bs * 64 * 4 > 0xffffffffll) return HSP_EINVAL;       // the kernels address the spectrum with 32-bit byte offsets
+  const DsGeom Gf = ds_geom(a, false), Gi = ds_geom(a, true);
+  const size_t lds_f = ((size_t)Gf.bufsz + 64 + (act ? 32 + 4 * DA_SLICE : 0)) * sizeof(float);
+  const size_t lds_i = ((size_t)Gi.bufsz + 128 * 32) * sizeof(float);
+  if (lds_f > 160 * 1024 || lds_i > 160 * 1024) return HSP_EINVAL;
+  if ((int64_t)a.B * Gf.ngrp * Gf.nchunk > 0x7fffffff || (int64_t)a.B * Gi.ngrp * Gi.nchunk > 0x7fffffff) return HSP_EINVAL;
+  return 0;
+}
 }  // namespace
+
+extern "C" int hsp_dftseg_supported(const hsp_dftseg_args* ap) {
+  if (!ap) return 0;
+  hsp_dftseg_args a = *ap;
+  static const float dummy = 0.0f;                              // ds_check wants non-null pointers; none is read
+  a.xf = const_cast<float*>(&dummy);
+  a.dft = &dummy;
+  return ds_check(a) == 0 && ds_limits(a, true) == 0 ? 1 : 0;
+}
 
 extern "C" int hsp_dftseg_tables_f32(float* fwd, float* inv) {
   if (!fwd || !inv) return HSP_EINVAL;

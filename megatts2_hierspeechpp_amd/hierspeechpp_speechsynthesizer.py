@@ -190,16 +190,45 @@ def fft_eligible(channels: int, k: int, dilation: int) -> bool:
 
 def fft_min_cols(channels: int, k: int) -> int:
     """Samples per channel (batch x length) from which the frequency-domain form wins: its product launch reads one
-    [2C][2C] matrix per bin (268 MB at 512 channels) and there are three launches, a floor that a single short utterance
+    matrix set per bin (201 MB at 512 channels) and there are three launches, a floor that a single short utterance
     does not amortise (profiles/r04_fftconv_batch.txt: 0.19 ms at 512 channels whatever the batch is, up to 8 x 4 s)."""
+    if FFT_MIN_COLS is not None:
+        return FFT_MIN_COLS
     if k >= 11:
         return 6400 if channels >= 512 else 8000 if channels >= 256 else 32000 if channels >= 128 else 256000
     return 6400 if channels >= 512 else 16000 if channels >= 256 else 128000
 
 
+# HSP_FFT_MIN_COLS=<n> (or the module attribute) replaces the measured thresholds above; 0 forces the form on every
+# eligible conv whatever the batch is -- the parity tests run the reference-generated fixtures through the frequency-domain
+# kernels that way (tests/test_gpu_parity.py::test_golden_frequency_domain_forced).
+FFT_MIN_COLS = int(os.environ["HSP_FFT_MIN_COLS"]) if os.environ.get("HSP_FFT_MIN_COLS") else None
+_WARNED_CAPTURE = False
+
+
 def fft_wins(conv, x) -> bool:
-    return (FFT_CONV and getattr(conv, "_wf", None) is not None and x.stride(2) == 1
-            and x.shape[0] * x.shape[2] >= fft_min_cols(conv.cin, conv.k))
+    """Does this call take the conv's frequency-domain form?  Eligible by shape (enable_fft), enough samples per channel
+    for the form to pay (fft_min_cols), a geometry the transform kernels address (hsp_dftseg_supported: the reference has no
+    batch or length limit, hierspeechpp_speechsynthesizer.py:377-386,635-651, so beyond it the direct conv runs), and --
+    inside a stream capture -- per-bin matrices that already exist (they are derived on first eager use)."""
+    if not (FFT_CONV and conv.__dict__.get("_fft") and x.stride(2) == 1):
+        return False
+    B, _, Lx = x.shape
+    if B * Lx < fft_min_cols(conv.cin, conv.k):
+        return False
+    ok = conv.__dict__.setdefault("_fft_ok", {})
+    sup = ok.get((B, Lx))
+    if sup is None:
+        sup = ok[(B, Lx)] = conv.fft_supported(B, Lx)
+    if sup and conv._wf is None and torch.cuda.is_current_stream_capturing():
+        global _WARNED_CAPTURE
+        if not _WARNED_CAPTURE:
+            _WARNED_CAPTURE = True
+            import warnings
+            warnings.warn("a stream capture met a conv whose frequency-domain matrices were never derived: it takes the "
+                          "direct form inside this graph (run one eager call or hip_layers.prepare_fft(model) first)")
+        return False
+    return sup
 
 
 FFT_ACT = os.environ.get("HSP_FFT_ACT", "1") == "1"   # 0: the activation stays its own launch (A/B runs)

@@ -59,6 +59,25 @@ def _dft_tables(device):
     return t
 
 
+_TW = {}
+
+
+def _wspec_twiddles(device):
+    """256 float64 values in device memory, cos(2 pi n / 128) then sin, n < 128: the table of
+    hsp_dftseg_weight_spectrum_f32 (include/hsp.h), generated here in float64."""
+    t = _TW.get(device)
+    if t is None:
+        ang = 2.0 * np.pi * np.arange(128, dtype=np.float64) / 128.0
+        t = _TW[device] = torch.from_numpy(np.concatenate([np.cos(ang), np.sin(ang)])).to(device)
+    return t
+
+
+# The channel product between the two transforms: "three" = hsp_cprod3_f32 (round 5: three real C x C products per bin,
+# 6 C^2 flops per column and 3 C^2 weights per bin), "block" = round 4's [2C x 2C] real block matrix per bin on the conv
+# kernel (hsp_conv1d_args.w_bs; 8 C^2 / 4 C^2) -- kept for A/B runs and for channel counts that are not multiples of 64.
+FFT_PRODUCT = os.environ.get("HSP_FFT_PRODUCT", "three")
+
+
 def fft_act_fusable(x) -> bool:
     """hsp_dftseg_args.act_*: the fused activation reads 16-B groups of every row."""
     return (x.stride(2) == 1 and x.shape[2] % 4 == 0 and x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0
@@ -315,6 +334,7 @@ class _ConvBase(HipLayer):
         self.wn = weight_norm
         self._w: Optional[torch.Tensor] = None
         self._b: Optional[torch.Tensor] = None
+        self._wf: Optional[torch.Tensor] = None     # per-bin matrices of the frequency-domain form (Conv1d.ensure_wf)
 
     def _folded(self) -> torch.Tensor:
         if self.wn:
@@ -371,17 +391,39 @@ class Conv1d(_ConvBase):
         fused = self.__dict__.get("_pre_norm") is not None
         return [("w", self.k * self.cin * self.M)] + ([("b", self.cout)] if self.has_bias or fused else []) + \
             ([("c1", self.cout)] if fused else []) + \
-            ([("wt", self.cout * self.cin)] if self.__dict__.get("_rowmajor") else []) + \
-            ([("wf", 64 * 4 * self.cin * self.cout)] if self.__dict__.get("_fft") else [])
+            ([("wt", self.cout * self.cin)] if self.__dict__.get("_rowmajor") else [])
 
     def enable_fft(self):
-        """Also pack the frequency-domain form of this same-length stride-1 conv (round 4, csrc/hsp_dftseg.hip): per
-        frequency bin of a 128-point transform the real block matrix [[Wr, Wi], [-Wi, Wr]] of conj(rfft(w)); bin 0
-        holds DC and Nyquist.  ``forward_fft`` then computes the conv as forward DFT -> one batched 1x1 product -> inverse
-        DFT: 2.2 multiply-adds per output and channel pair instead of k."""
+        """This same-length stride-1 conv may also run in its frequency-domain form (round 4, csrc/hsp_dftseg.hip):
+        ``forward_fft`` computes it as forward DFT -> one batched channel product over the 64 bins -> inverse DFT, 1.7 (2.2
+        in the block form) multiply-adds per output and channel pair instead of k.  The per-bin matrices of conj(rfft(w,
+        128)) are DERIVED data: they are not part of the weight arena (what a multi-GPU job broadcasts) but
+        a side buffer that ``ensure_wf`` fills from the packed taps on first use, on every rank, with
+        hsp_dftseg_weight_spectrum_f32 -- a model that never meets a batch large enough for the form (fft_wins) never
+        allocates them (201 MB per conv at 512 channels)."""
         assert self.stride == 1 and self.rows == L.ROWS_PLAIN and self.cin == self.cout and 2 <= self.k <= 64
         assert self.padding * 2 == (self.k - 1) * self.dilation, "same-length conv"
         self.__dict__["_fft"] = True
+
+    def fft_form(self) -> str:
+        return "three" if FFT_PRODUCT == "three" and self.cin % 64 == 0 else "block"
+
+    def ensure_wf(self):
+        """The per-bin matrices of this conv's channel product, derived on the device from the packed taps (``_w``:
+        [k][C][M]) in float64 and rounded once: [64][3][C][C] = (a + b, a, b) of conj(W) = a + i b for hsp_cprod3_f32, or
+        round 4's [64][2C][2C] block matrices.  Deterministic: every rank derives the same bits from the same taps."""
+        if self._wf is not None:
+            return self._wf
+        self._require_ready()
+        if torch.cuda.is_current_stream_capturing():
+            raise L.HspError("ensure_wf() inside a stream capture: run one eager call first (or prepare_fft(model))")
+        Cc, form = self.cin, self.fft_form()
+        wf = torch.empty(64 * (3 if form == "three" else 4) * Cc * Cc, dtype=torch.float32, device=self._w.device)
+        L.check(L.lib().hsp_dftseg_weight_spectrum_f32(
+            L.fptr(self._w), self.k, Cc, self.M, L.ptr(_wspec_twiddles(self._w.device)), L.fptr(wf),
+            L.WSPEC_THREE if form == "three" else L.WSPEC_BLOCK, L.stream_ptr()), "hsp_dftseg_weight_spectrum_f32")
+        self._wf, self._wf_form = wf, form
+        return wf
 
     def hsp_fill(self, arena, materialize):
         if self.__dict__.get("_stacked_elsewhere"):
@@ -391,25 +433,12 @@ class Conv1d(_ConvBase):
         self._b = arena.view(self, "b") if self.has_bias or fused else None
         self._c1 = arena.view(self, "c1") if fused else None
         self._wt = arena.view(self, "wt").view(self.cout, self.cin) if self.__dict__.get("_rowmajor") else None
-        self._wf = arena.view(self, "wf") if self.__dict__.get("_fft") else None
+        self._wf = None                                   # derived from _w on first use (ensure_wf)
         if materialize:
             w = self._folded()
             if self._wt is not None:
                 assert not fused
                 self._wt.copy_(w.reshape(self.cout, self.cin))
-            if self._wf is not None:
-                # conj(rfft(w)) per (co, ci) in float64; packed per bin as w[ci'][m'] (the conv kernel's [Cin][M] layout)
-                Cc = self.cin
-                wf = torch.fft.rfft(torch.nn.functional.pad(w.double(), (0, 128 - self.k)), dim=2)     # [co, ci, 65]
-                wr, wi = wf.real.permute(2, 1, 0), wf.imag.permute(2, 1, 0)                               # [bin, ci, co]
-                blk = self._wf.view(64, 2 * Cc, 2 * Cc)
-                blk[:, :Cc, :Cc] = wr[:64].float()          # Yr += Wr Xr
-                blk[:, Cc:, :Cc] = wi[:64].float()          # Yr += Wi Xi
-                blk[:, :Cc, Cc:] = -wi[:64].float()         # Yi -= Wi Xr
-                blk[:, Cc:, Cc:] = wr[:64].float()          # Yi += Wr Xi
-                blk[0, Cc:, :Cc] = 0.0                      # bin 0: DC (part 0) and Nyquist (part 1) do not mix
-                blk[0, :Cc, Cc:] = 0.0
-                blk[0, Cc:, Cc:] = wr[64].float()
             if fused:
                 g, beta = self._ln_params()
                 w2 = w.reshape(self.cout, self.cin).double()
@@ -435,7 +464,17 @@ class Conv1d(_ConvBase):
         da.B, da.C, da.L, da.k, da.dil, da.pad, da.nseg = B, self.cin, Lx, k, d, self.padding, nseg
         da.Np = _round_up(B * d * nseg, 4)
         da.post_scale = 1.0
+        da.prod3 = int(self.fft_form() == "three")
         return da
+
+    def fft_supported(self, B, Lx) -> bool:
+        """Do the transform kernels take this geometry (hsp_dftseg_supported: dilation <= 8, a spectrum below 4 GiB per
+        launch, item counts within int)?  fft_wins asks before choosing the form; beyond it the direct conv runs."""
+        if not self.__dict__.get("_fft"):
+            return False
+        da = self._fft_args(B, Lx)
+        da.xf_bs = 2 * self.cin * da.Np
+        return bool(L.lib().hsp_dftseg_supported(C.byref(da)))
 
     @staticmethod
     def _fft_set_act(da, x_like, act1d):
@@ -446,7 +485,7 @@ class Conv1d(_ConvBase):
     def _fft_forward(self, x, act1d=None):
         """x [B, C, L] -> spectrum [64][2 C][Np] (hsp_dftseg_fwd_f32), the activation applied on the way if given."""
         B, Cc, Lx = x.shape
-        assert Cc == self.cin and x.stride(2) == 1 and self._wf is not None
+        assert Cc == self.cin and x.stride(2) == 1 and self.__dict__.get("_fft")
         da = self._fft_args(B, Lx)
         xf = torch.empty(64, 2 * Cc, da.Np, dtype=torch.float32, device=x.device)
         da.x, da.x_bs, da.x_cs = L.fptr(x), x.stride(0), x.stride(1)
@@ -466,13 +505,28 @@ class Conv1d(_ConvBase):
         return xf, (ev[0] if ev else None)
 
     def _fft_product(self, xf):
-        """ONE batched 1x1 launch over the 64 bins: yf[bin] = [[Wr, Wi], [-Wi, Wr]][bin] xf[bin]."""
+        """ONE batched launch over the 64 bins: yf[bin] = conj(W)[bin] xf[bin] -- three real C x C products per bin
+        (hsp_cprod3_f32) or the [2C x 2C] block matrix [[Wr, Wi], [-Wi, Wr]] on the conv kernel."""
         Cc, Np = self.cin, xf.shape[2]
+        wf = self.ensure_wf()
         yf = torch.empty_like(xf)
+        if self._wf_form == "three":
+            pa = L.Cprod3Args()
+            pa.xf, pa.yf, pa.w, pa.zeros = L.fptr(xf), L.fptr(yf), L.fptr(wf), L.fptr(_zeros(xf.device))
+            pa.xf_bs, pa.yf_bs, pa.bins, pa.C, pa.Np = xf.stride(0), yf.stride(0), 64, Cc, Np
+            hook = LAUNCH_HOOK
+            if hook is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            L.check(L.lib().hsp_cprod3_f32(C.byref(pa), L.stream_ptr()), "hsp_cprod3_f32")
+            if hook is not None:
+                e1.record()
+                hook("hsp_cprod3_f32", 2 * 64 * 3 * Cc * Cc * Np, 4 * (64 * 2 * 2 * Cc * Np + 64 * 3 * Cc * Cc), e0, e1, None)
+            return yf
         a = L.Conv1dArgs()
         a.x, a.x_bs, a.x_cs, a.x_ts = L.fptr(xf), xf.stride(0), xf.stride(1), 1
         a.B, a.Cin, a.Lin = 64, 2 * Cc, Np
-        a.w, a.K, a.dil, a.pad, a.stride = L.fptr(self._wf), 1, 1, 0, 1
+        a.w, a.K, a.dil, a.pad, a.stride = L.fptr(wf), 1, 1, 0, 1
         a.M, a.w_ld, a.w_bs = 2 * Cc, 2 * Cc, 4 * Cc * Cc
         a.zeros = L.fptr(_zeros(xf.device))
         _set_out(a, yf, 64, 2 * Cc, Np)
@@ -533,7 +587,7 @@ class Conv1d(_ConvBase):
     def fft_pair_ok(self, second, x) -> bool:
         """Can the inverse transform of this conv be fused with the activation and the forward transform of ``second``
         (hsp_dftseg_pair_f32) for an input like x?  Both unchunked and their two LDS stretches within one CU's 160 KB."""
-        if self._wf is None or second._wf is None or second.cin != self.cin or x.shape[2] % 4:
+        if not self.__dict__.get("_fft") or not second.__dict__.get("_fft") or second.cin != self.cin or x.shape[2] % 4:
             return False
         B, _, Lx = x.shape
         ia, fa = self._fft_args(B, Lx), second._fft_args(B, Lx)
@@ -901,6 +955,17 @@ def _set_epilogue(a, act, cbias, mask, mask_mode, cscale, scale, res, accumulate
             a.res_ts = res.stride(2)      # hsp_conv1d_args.res_ts: the register-path token GEMM only (else HSP_EINVAL)
     a.accumulate = 1 if accumulate else 0
     a.post_scale = float(post_scale)
+
+
+def prepare_fft(model: nn.Module) -> int:
+    """Derive the per-bin matrices of every conv of ``model`` that carries the frequency-domain form now (Conv1d.ensure_wf
+    does it on first use otherwise) -- before a hipGraph capture, or to pay the start-up cost at a chosen moment.  Returns
+    the number of floats the side buffers hold."""
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Conv1d) and m.__dict__.get("_fft"):
+            n += m.ensure_wf().numel()
+    return n
 
 
 # ------------------------------------------------------------------ finalisation

@@ -71,7 +71,8 @@ def barrier() -> None:
         dist.barrier()
 
 
-def finalize_distributed(model, device, src: int = 0, timings: dict = None, force_collective: bool = False):
+def finalize_distributed(model, device, src: int = 0, timings: dict = None, force_collective: bool = False,
+                         derive: bool = True):
     """Rank ``src`` folds + packs the weights; every other rank only lays the arena out
     (identical offsets by construction) and receives the bytes by broadcast.
 
@@ -79,7 +80,9 @@ def finalize_distributed(model, device, src: int = 0, timings: dict = None, forc
     ``broadcast_ms`` -- the ``dist.broadcast`` loop alone, bracketed by a barrier and device synchronisation on both
     sides so that it starts when the slowest rank is ready and ends when the last byte has landed; ``None`` at
     world size 1 (no collective runs) unless ``force_collective`` / FORCE_COLLECTIVES asks for the broadcast branch on
-    a one-rank group (the process group must exist: ``init_distributed(force=True)``)."""
+    a one-rank group (the process group must exist: ``init_distributed(force=True)``).  ``derive``: every rank then
+    derives the per-bin matrices of the frequency-domain convs from the taps it now holds (``derive_ms``,
+    ``derived_mb``; ``broadcast_mb`` = the arena that travelled) instead of leaving that to the first call."""
     import time
     multi = collectives_on() or (force_collective and dist.is_initialized())
     on_gpu = torch.device(device).type == "cuda"
@@ -103,8 +106,21 @@ def finalize_distributed(model, device, src: int = 0, timings: dict = None, forc
         sync()
         dist.barrier()
         bc_ms = 1e3 * (time.perf_counter() - t0)
+    # Derived data stays off the wire (the broadcast carries the folded weights, ~457 MB for the vocoder):
+    # the per-bin matrices of the frequency-domain convs (3.6 GB at 42 convs) are computed from the broadcast taps by EVERY
+    # rank with the same kernel (hsp_dftseg_weight_spectrum_f32), bit-identical across ranks.
+    derive_ms = derived_mb = None
+    if derive and on_gpu:
+        from . import hip_layers
+        t0 = time.perf_counter()
+        with torch.cuda.device(device):
+            n = hip_layers.prepare_fft(model)
+        sync()
+        derive_ms, derived_mb = 1e3 * (time.perf_counter() - t0), n * 4 / 1e6
     if timings is not None:
         timings["pack_ms"], timings["broadcast_ms"] = pack_ms, bc_ms
+        timings["broadcast_mb"] = arena.buffer.numel() * 4 / 1e6 if getattr(arena, "buffer", None) is not None else None
+        timings["derive_ms"], timings["derived_mb"] = derive_ms, derived_mb
     return arena
 
 

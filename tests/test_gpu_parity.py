@@ -499,17 +499,18 @@ def test_bench_force_dist_line_on_device(device):
     assert line["config"]["shard_of_rank0"] == [0, 2] and line["value"] > 0
 
 
-def test_layout_only_rank_reproduces_rank0(device):
+def test_layout_only_rank_reproduces_rank0(device, monkeypatch):
     """What a rank other than the broadcast source does in a multi-GPU job (parallel.finalize_distributed): lay the
     weight arena out without the weights (materialize=False), receive rank 0's bytes, run.  Emulated in one process
     by copying the arena buffer; the outputs must equal rank 0's bit for bit.  Covers the vocoder (weight-norm folds,
     polyphase ConvTranspose packs, fused pairs), the SpeechSR head and the denoiser (sub-layers that live inside other
     layers and are filled from their parents' parameters)."""
-    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd import hip_layers, synth
     from megatts2_hierspeechpp_amd.denoiser.generator import MPNet
     from megatts2_hierspeechpp_amd.denoiser.infer import denoise
     from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import SynthesizerTrn
     from oracle.hsp_oracle import default_config
+    ar_specs = []
 
     def pair(make):
         a, b = make(), make()
@@ -519,6 +520,7 @@ def test_layout_only_rank_reproduces_rank0(device):
         ar_a, ar_b = a._hsp_arena, b._hsp_arena
         assert ar_a.total == ar_b.total and [sp[1:] for sp in ar_a.specs] == [sp[1:] for sp in ar_b.specs]
         ar_b.buffer.copy_(ar_a.buffer)                     # the RCCL broadcast
+        ar_specs[:] = ar_a.specs
         return a, b
 
     voc_a, voc_b = pair(lambda: SynthesizerTrn(641, 192, **default_config()))
@@ -527,6 +529,19 @@ def test_layout_only_rank_reproduces_rank0(device):
     oa, ea = voc_a.infer(*args, noise=inp["noise"])
     ob, eb = voc_b.infer(*args, noise=inp["noise"])
     assert torch.equal(oa, ob) and torch.equal(ea, eb)
+    # (round 5) the per-bin matrices of the frequency-domain convs are NOT in the arena: every rank derives them from the
+    # taps it received (hsp_dftseg_weight_spectrum_f32) -- forced on at this small size, the two ranks still agree bit for bit
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    monkeypatch.setattr(hss, "FFT_MIN_COLS", 0)
+    kinds = []
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", lambda kind, *a: kinds.append(kind))
+    of, _ = voc_a.infer(*args, noise=inp["noise"])
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", None)
+    og, _ = voc_b.infer(*args, noise=inp["noise"])
+    assert "hsp_cprod3_f32" in kinds and "hsp_dftseg_pair_f32" in kinds
+    assert torch.equal(of, og)
+    assert float((of - oa).abs().max()) <= 5e-5           # two fp32 routes to the same audio (each within 1e-4 of the reference)
+    assert sum(sp[2] for sp in ar_specs) * 4 < 500e6, "the broadcast arena holds the folded weights only (SURVEY.md 8e: ~457 MB)"
 
     den_a, den_b = pair(lambda: MPNet(H.DENOISER_H))
     g = torch.Generator().manual_seed(12)
@@ -1735,3 +1750,168 @@ def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, k2, device):
 
 
 
+
+
+# ------------------------------------------------------------------ (round 5) three-product channel mix, derived weights, guards
+def _fft_layer(C_, k, d, g, device):
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d, finalize
+    lay = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
+    with torch.no_grad():
+        for p_ in lay.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g))
+        lay.weight_g.fill_(0.5)
+    lay.enable_fft()
+    w = (lay.weight_g.data * lay.weight_v.data / lay.weight_v.data.flatten(1).norm(dim=1).view(-1, 1, 1)).double()
+    bias = lay.bias.data.clone().double()
+    finalize(lay, device)
+    return lay, w, bias
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,k", [(64, 11), (128, 7), (48, 5), (64, 63)])
+def test_weight_spectrum_kernel_vs_rfft(C_, k, device, monkeypatch):
+    """hsp_dftseg_weight_spectrum_f32: the per-bin matrices of a conv's channel product derived ON THE DEVICE from the
+    packed taps (float64 DFT sums, one rounding) against numpy's rfft of the same fp32 taps in float64 -- both layouts:
+    [64][3][C][C] = (a + b, a, b) of conj(W) = a + i b with (0, W_nyquist, W_dc) in slot 0 (hsp_cprod3_f32), and round 4's
+    [64][2C][2C] block matrices.  Within one fp32 ulp (the summation orders differ in float64 only)."""
+    from megatts2_hierspeechpp_amd import hip_layers
+    g = torch.Generator().manual_seed(9 * C_ + k)
+    lay, _, _ = _fft_layer(C_, k, 1, g, device)
+    taps = lay._w.view(k, C_, lay.M)[:, :, :C_].cpu().double().numpy()        # [tap][ci][m]
+    W = np.fft.rfft(np.pad(taps, ((0, 128 - k), (0, 0), (0, 0)), mode="constant"), axis=0)   # [65][ci][m]
+    a_, b_ = W.real, -W.imag                                                    # conj(W) = a + i b
+    for prod in ("three", "block"):
+        monkeypatch.setattr(hip_layers, "FFT_PRODUCT", prod)
+        lay._wf = None
+        wf = lay.ensure_wf().cpu().numpy()
+        if lay.fft_form() == "three":
+            assert C_ % 64 == 0
+            got = wf.reshape(64, 3, C_, C_)
+            want = np.stack([a_[:64] + b_[:64], a_[:64], b_[:64]], axis=1)
+            want[0, 0], want[0, 1], want[0, 2] = 0.0, W[64].real, W[0].real
+        else:
+            got = wf.reshape(64, 2 * C_, 2 * C_)
+            want = np.zeros((64, 2 * C_, 2 * C_))
+            want[:, :C_, :C_], want[:, C_:, :C_] = a_[:64], -b_[:64]            # Yr += Wr Xr, Yr += Wi Xi   (Wi = -b)
+            want[:, :C_, C_:], want[:, C_:, C_:] = b_[:64], a_[:64]             # Yi -= Wi Xr, Yi += Wr Xi
+            want[0] = 0.0
+            want[0, :C_, :C_], want[0, C_:, C_:] = W[0].real, W[64].real
+        err = np.abs(got - want.astype(np.float32))
+        assert float((err / np.maximum(np.abs(want), 1.0)).max()) <= 1.2e-7, (prod, float(err.max()))
+    assert C_ % 64 == 0 or lay.fft_form() == "block"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,k,d,L,B", [(64, 11, 1, 3000, 2), (128, 7, 3, 1000, 3), (256, 11, 5, 500, 2), (512, 7, 1, 52, 2),
+                                        (64, 11, 1, 32000, 1), (192, 7, 1, 700, 2)])
+def test_three_product_channel_mix_vs_block_form(C_, k, d, L, B, device, monkeypatch):
+    """Conv1d.forward_fft with the channel product as three real C x C products per bin (hsp_cprod3_f32, round 5) against
+    the same conv with round 4's [2C x 2C] block matrix on the conv kernel and against torch's float64 conv
+    (hierspeechpp_speechsynthesizer.py:349-364: the C x C channel mix of the AMP convs).  Column counts on and off the
+    128-column tile, one to eight row tiles, 4 ... 32 chunks of input channels."""
+    from megatts2_hierspeechpp_amd import hip_layers
+    g = torch.Generator().manual_seed(C_ + 13 * k + d + L)
+    lay, w, bias = _fft_layer(C_, k, d, g, device)
+    x = torch.randn(B, C_, L, generator=g)
+    res = torch.randn(B, C_, L, generator=g)
+    ref = torch.nn.functional.conv1d(x.double(), w, bias, dilation=d, padding=(k - 1) * d // 2) + res.double()
+    dx, dres = x.to(device), res.to(device)
+    out = {}
+    for prod in ("three", "block"):
+        monkeypatch.setattr(hip_layers, "FFT_PRODUCT", prod)
+        lay._wf = None
+        kinds = []
+        monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", lambda kind, *a: kinds.append(kind))
+        out[prod] = lay.forward_fft(dx, res=dres).cpu()
+        monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", None)
+        assert ("hsp_cprod3_f32" in kinds) == (prod == "three")
+        _close(out[prod].numpy(), ref.float().numpy(), f"fft conv, {prod} product, C={C_} k={k} d={d} L={L}")
+    scale = max(1.0, float(ref.abs().max()))
+    e3, eb = float((out["three"] - ref.float()).abs().max()), float((out["block"] - ref.float()).abs().max())
+    assert float((out["three"] - out["block"]).abs().max()) <= 1e-5 * scale
+    assert e3 <= 3.0 * eb + 2e-6 * scale, f"three-product error {e3:.2e} against the block form's {eb:.2e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["generator", "infer_config1", "infer_ragged", "vc_noise_control"])
+def test_golden_frequency_domain_forced(name, device, monkeypatch):
+    """The reference-generated vectors through the frequency-domain kernels: with HSP_FFT_MIN_COLS = 0 every eligible AMP
+    conv of the Generator takes the form at fixture sizes too (forward transform with the fused activation, three-product
+    channel mix, pair launch, inverse), and the golden outputs are met as by the direct convs."""
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from megatts2_hierspeechpp_amd import hip_layers
+    if name not in H.fixture_names():
+        pytest.skip(f"no fixture {name}")
+    monkeypatch.setattr(hss, "FFT_MIN_COLS", 0)
+    kinds = []
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", lambda kind, *a: kinds.append(kind))
+    meta, arrays = H.load_fixture(name)
+    outs = H.run_hip(meta, arrays, device)
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", None)
+    assert kinds.count("hsp_cprod3_f32") >= 20 and "hsp_dftseg_fwd_f32" in kinds and "hsp_dftseg_inv_f32" in kinds, \
+        "the fixture did not reach the frequency-domain form"
+    for i, (o, r) in enumerate(zip(outs, H.outputs(arrays))):
+        _close(o, r, f"{name}[{i}] (frequency-domain form forced)")
+
+
+@pytest.mark.gpu
+def test_frequency_domain_conv_dynamic_range(device):
+    """A 0 dB burst beside -60 dB noise in one 128-channel row.  An overlap-save segment carries rounding errors that scale
+    with ITS loudest sample, so the quiet outputs that share a 128-sample segment with the burst see an error relative to
+    the burst, not to themselves; everything further away is as accurate as the direct conv.  Reported on the quiet half
+    against the quiet half's own peak, next to the direct conv's figure, and bounded: the leak stays inside the segments
+    that contain loud samples and is below 1e-6 of the burst's output level (the 1e-4 bar on the whole tensor holds with
+    two orders to spare)."""
+    g = torch.Generator().manual_seed(60)
+    C_, k, d, L, cut = 128, 11, 1, 4000, 2000
+    lay, w, bias = _fft_layer(C_, k, d, g, device)
+    x = torch.randn(1, C_, L, generator=g)
+    x[:, :, cut:] *= 1e-3
+    ref = torch.nn.functional.conv1d(x.double(), w, None, dilation=d, padding=(k - 1) * d // 2)
+    lay._b.zero_()                                               # (the bias would swamp the quiet half)
+    dx = x.to(device)
+    fft, direct = lay.forward_fft(dx).cpu().double(), lay(dx).cpu().double()
+    loud_peak, quiet = float(ref[:, :, :cut].abs().max()), slice(cut + k * d, L)
+    quiet_peak = float(ref[:, :, quiet].abs().max())
+    far = slice(cut + 128 * d + k * d, L)                        # no segment out here contains a loud sample
+    e_fft_q, e_dir_q = float((fft - ref)[:, :, quiet].abs().max()), float((direct - ref)[:, :, quiet].abs().max())
+    e_fft_far, e_dir_far = float((fft - ref)[:, :, far].abs().max()), float((direct - ref)[:, :, far].abs().max())
+    print(f"quiet half (peak {quiet_peak:.2e}, burst output peak {loud_peak:.2e}): frequency-domain {e_fft_q / quiet_peak:.2e} "
+          f"of its own peak (direct conv {e_dir_q / quiet_peak:.2e}); beyond the burst's segments {e_fft_far / quiet_peak:.2e} "
+          f"(direct {e_dir_far / quiet_peak:.2e})")
+    _close(fft.float().numpy(), ref.float().numpy(), "burst beside noise, whole tensor")
+    assert e_fft_q <= 2e-6 * loud_peak, "leak of the burst's rounding error into the quiet samples of its segments"
+    assert e_fft_far <= 2e-5 * quiet_peak and e_dir_q <= 2e-5 * quiet_peak
+
+
+@pytest.mark.gpu
+def test_frequency_domain_form_falls_back_beyond_its_addressing(device, monkeypatch):
+    """482 x 4 s at the 128-channel stage: the spectrum of one launch would pass 4 GiB, which the transform kernels do not
+    address (hsp_dftseg_supported).  The reference has no batch limit (hierspeechpp_speechsynthesizer.py:377-386,635-651):
+    the AMP block must take the direct convs there -- no HspError, no transform launch -- and give exactly what it gives
+    with the form switched off; one utterance fewer and the form is back."""
+    from megatts2_hierspeechpp_amd import activations
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from megatts2_hierspeechpp_amd import hip_layers
+    g = torch.Generator().manual_seed(482)
+    blk = hss.AMPBlock1(128, 11, (1,), activation="snakebeta")
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            p_.copy_(0.3 * torch.randn(p_.shape, generator=g))
+        for c in list(blk.convs1) + list(blk.convs2):
+            c.weight_g.fill_(0.5)
+    hip_layers.finalize(blk, device)
+    x = torch.randn(482, 128, 16000, generator=g).to(device)
+    assert not hss.fft_wins(blk.convs1[0], x) and hss.fft_wins(blk.convs1[0], x[:481])
+    kinds = []
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", lambda kind, *a: kinds.append(kind))
+    y = blk(x)
+    assert not any(kd.startswith("hsp_dftseg") or kd == "hsp_cprod3_f32" for kd in kinds), kinds
+    kinds.clear()
+    y481 = blk(x[:481])
+    assert "hsp_dftseg_pair_f32" in kinds and "hsp_cprod3_f32" in kinds
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", None)
+    monkeypatch.setattr(hss, "FFT_CONV", False)
+    yd = blk(x)
+    assert torch.equal(y, yd)
+    assert float((y481 - yd[:481]).abs().max()) <= 2e-5 * max(1.0, float(yd.abs().max()))

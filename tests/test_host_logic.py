@@ -169,6 +169,9 @@ def test_ctypes_structs_match_the_header(tmp_path):
     fields_d = [f for f, _ in _lib.DftSegArgs._fields_]
     lines += ['printf("%zu\\n", sizeof(hsp_dftseg_args));']
     lines += [f'printf("%zu\\n", offsetof(hsp_dftseg_args, {f}));' for f in fields_d]
+    fields_3 = [f for f, _ in _lib.Cprod3Args._fields_]
+    lines += ['printf("%zu\\n", sizeof(hsp_cprod3_args));']
+    lines += [f'printf("%zu\\n", offsetof(hsp_cprod3_args, {f}));' for f in fields_3]
     lines += ["return 0;}"]
     src.write_text("\n".join(lines))
     exe = tmp_path / "abi"
@@ -178,6 +181,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     want += [ctypes.sizeof(_lib.MhaArgs)] + [getattr(_lib.MhaArgs, f).offset for f in fields_m]
     want += [ctypes.sizeof(_lib.MhaProjArgs)] + [getattr(_lib.MhaProjArgs, f).offset for f in fields_p]
     want += [ctypes.sizeof(_lib.DftSegArgs)] + [getattr(_lib.DftSegArgs, f).offset for f in fields_d]
+    want += [ctypes.sizeof(_lib.Cprod3Args)] + [getattr(_lib.Cprod3Args, f).offset for f in fields_3]
     assert vals == want
 
 
@@ -384,3 +388,58 @@ def test_dftseg_tables_give_the_128_point_real_transform_and_its_inverse():
     y = np.zeros(128)
     y[0::2], y[1::2] = Mi @ Eb, Mi @ Ob
     assert np.abs(y - x).max() < 1e-6
+
+
+def test_frequency_domain_form_has_a_supported_predicate():
+    """hsp_dftseg_supported (include/hsp.h): the transform kernels address a launch's spectrum with 32-bit byte offsets
+    (C Np <= 8.4 M), take dilations up to 8 and int item counts; the reference has no batch or length limit
+    (hierspeechpp_speechsynthesizer.py:377-386,635-651), so fft_wins consults the predicate and keeps the direct conv
+    beyond it.  Host logic only: the predicate reads geometry, no device."""
+    import ctypes as C
+    from megatts2_hierspeechpp_amd import _lib as L
+    from megatts2_hierspeechpp_amd.hip_layers import Conv1d
+
+    def geom(C_, k, d, B, Lx):
+        lay = Conv1d(C_, C_, k, dilation=d, padding=(k - 1) * d // 2, weight_norm=True)
+        lay.enable_fft()
+        da = lay._fft_args(B, Lx)
+        da.xf_bs = 2 * C_ * da.Np
+        return lay, da
+
+    lib = L.lib()
+    for C_, k, d, B, Lx in ((512, 11, 5, 32, 800), (128, 7, 1, 32, 16000), (64, 11, 3, 32, 32000), (256, 11, 1, 1, 50)):
+        lay, da = geom(C_, k, d, B, Lx)
+        assert lib.hsp_dftseg_supported(C.byref(da)) == 1 and lay.fft_supported(B, Lx)
+    # B = 482 x 4 s at the 128-channel stage: 482 x 136 segments x 128 channels > 8.4 M spectrum columns x rows
+    lay, da = geom(128, 11, 1, 482, 16000)
+    assert 128 * da.Np > 0xffffffff // 1024 and lib.hsp_dftseg_supported(C.byref(da)) == 0 and not lay.fft_supported(482, 16000)
+    lay, da = geom(128, 11, 1, 481, 16000)
+    assert lib.hsp_dftseg_supported(C.byref(da)) == 1
+    # one 17-minute utterance at 64 channels; a dilation the kernels do not carry; a wrong segment count
+    assert not geom(64, 11, 1, 1, 16_200_000)[0].fft_supported(1, 16_200_000)
+    assert not geom(64, 11, 9, 2, 4000)[0].fft_supported(2, 4000)
+    lay, da = geom(64, 11, 1, 2, 4000)
+    da.nseg += 1
+    assert lib.hsp_dftseg_supported(C.byref(da)) == 0
+    assert lib.hsp_dftseg_supported(None) == 0
+
+
+def test_three_product_weights_reproduce_the_complex_product():
+    """The algebra of hsp_cprod3_f32 in numpy (float64): with conj(W) = a + i b and the matrices (a + b, a, b),
+    k1 - k3 / k1 + k2 are the real / imaginary part of conj(W) X; slot 0 with (-E0, -O0) in the two planes and the
+    matrices (0, W_nyquist, W_dc) gives (W_dc DC, W_nyquist Nyquist) -- what hsp_dftseg_inv_f32 expects there."""
+    rng = np.random.default_rng(5)
+    C_, k, n = 6, 11, 9
+    w = rng.standard_normal((C_, C_, k))                        # [co, ci, tap]
+    W = np.fft.rfft(np.pad(w, ((0, 0), (0, 0), (0, 128 - k))), axis=2)   # [co, ci, 65]
+    X = rng.standard_normal((C_, n)) + 1j * rng.standard_normal((C_, n))
+    for b in (1, 17, 63):
+        a_, b_ = W[:, :, b].real, -W[:, :, b].imag              # conj(W) = a + i b
+        k1, k2, k3 = (a_ + b_) @ X.real, a_ @ (X.imag - X.real), b_ @ (X.real + X.imag)
+        ref = np.conj(W[:, :, b]) @ X
+        assert np.allclose(k1 - k3, ref.real) and np.allclose(k1 + k2, ref.imag)
+    E0, O0 = rng.standard_normal((C_, n)), rng.standard_normal((C_, n))
+    Wdc, Wny = W[:, :, 0].real, W[:, :, 64].real
+    xr, xi = -E0, -O0
+    k1, k2, k3 = 0.0 * xr, Wny @ (xi - xr), Wdc @ (xr + xi)
+    assert np.allclose(k1 - k3, Wdc @ (E0 + O0)) and np.allclose(k1 + k2, Wny @ (E0 - O0))
