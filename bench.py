@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_PROFILE = "r05_traffic.json"   # tools/pmc_traffic.sh + tools/pmc_summarize.py; quoted only when it matches this build
 METRIC = "16kHz audio samples/sec (whole node) + RTF, HierSpeech++ vocoder batch=32"
 
 VOC_CFG = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,
@@ -191,6 +192,8 @@ def run_bench(args, make_workload, backend="nccl", device=None):
     # dist.broadcast loop alone, max over ranks, None when no collective ran (world size 1)
     pack_ms = parallel.gather_floats(tm["pack_ms"], dev)[0]
     broadcast_ms = parallel.barrier_max(tm["broadcast_ms"], dev) if tm["broadcast_ms"] is not None else None
+    # derive_ms: every rank's own derivation of the frequency-domain matrices from the taps it holds (max over ranks)
+    derive_ms = parallel.barrier_max(tm["derive_ms"], dev) if tm.get("derive_ms") is not None else None
 
     n_utt = args.global_batch if getattr(args, "global_batch", None) else args.batch * world
     lo, hi = parallel.shard_range(n_utt, rank, world)
@@ -227,15 +230,17 @@ def run_bench(args, make_workload, backend="nccl", device=None):
     result = None
     if rank == 0:
         cfg = wl.describe(world)
-        cfg["weights_mb"] = arena.buffer.numel() * 4 / 1e6
+        cfg["weights_mb"] = arena.buffer.numel() * 4 / 1e6     # what travels (the folded weights); derived data is below
         cfg["shard_of_rank0"] = [lo, hi]
         cfg["global_batch"] = n_utt
         result = {
             "metric": METRIC, "value": samples_per_step * args.steps / elapsed, "unit": "samples/s",
             "rtf": (elapsed / args.steps) / audio_s_per_step, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
-            "pack_ms": pack_ms, "broadcast_ms": broadcast_ms,
+            "scaling": "strong" if getattr(args, "global_batch", None) else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": cfg,
+            "pack_ms": pack_ms, "broadcast_ms": broadcast_ms, "broadcast_mb": tm.get("broadcast_mb"),
+            "derive_ms": derive_ms, "derived_mb": tm.get("derived_mb"),
             "broadcast_gbs": (arena.buffer.numel() * 4 / 1e9) / (broadcast_ms * 1e-3) if broadcast_ms else None,
             "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)},
             "rccl_world": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend if coll else None,
@@ -325,17 +330,18 @@ def vocoder_roofline(args, wl, result):
     # a run from inside) and committed under profiles/.  Quoted only when that profile was taken on THIS build of
     # the library, with this workload and this launch mix; otherwise null, with the reason.
     traffic, traffic_note, tj = None, None, None
-    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     if not os.path.exists(path):
-        traffic_note = "no profiles/r04_traffic.json"
+        traffic_note = "no profiles/" + TRAFFIC_PROFILE
     else:
         with open(path) as fh:
             tj = json.load(fh)
         if tj.get("kernel_source_sha16") != _build_id():
             traffic_note, tj = f"profile taken on kernel sources {tj.get('kernel_source_sha16')}, this run uses {_build_id()}", None
-        elif (tj.get("batch_per_gpu"), tj.get("frames")) != (args.batch, wl.frames):
+        elif (tj.get("batch_per_gpu"), tj.get("frames")) != (wl.B, wl.frames):
             traffic_note, tj = "profile taken on another workload size", None
-        elif tj.get("conv1d_mfma_launches_per_step") != len(mf) or tj.get("act1d_launches_per_step") != len(act_rec):
+        elif tj.get("conv1d_mfma_launches_per_step") != len(mf) or tj.get("act1d_launches_per_step") != len(act_rec) or \
+                tj.get("cprod3_kernel_launches_per_step", 0) != sum(1 for r_ in rec if r_[0] == "hsp_cprod3_f32"):
             traffic_note, tj = "profile taken with another launch mix", None
         else:
             traffic = tj["conv1d_mfma_bytes_per_step"]["calibrated"] / len(mf)
@@ -348,7 +354,7 @@ def vocoder_roofline(args, wl, result):
                   % (len(tg), sum(m for _, _, m in tg)),
         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-        "traffic_source": "committed PMC profile profiles/r04_traffic.json (tools/pmc_traffic.sh; rocprofv3 cannot wrap a run "
+        "traffic_source": "committed PMC profile profiles/" + TRAFFIC_PROFILE + " (tools/pmc_traffic.sh; rocprofv3 cannot wrap a run "
                           "from inside), quoted only when its kernel-source hash, workload and launch mix equal this run's -- "
                           "not measured by this run",
         "algorithmic_bytes_per_launch": tot_b / max(len(mf), 1),
@@ -358,8 +364,15 @@ def vocoder_roofline(args, wl, result):
         "share_of_step_time_single_stream": tot_ms / result["ms_per_step"], "by_tile_shape": by_tile,
         "timing": "one extra step, the timed step's own launches serialised on one stream, event pair per launch",
     }
+    if tj:
+        # (round 5) the whole step's HBM bytes from the same committed PMC passes, class by class, against SURVEY.md 8(d)'s
+        # algorithmic bytes of the full infer path: which kernel owns the waste
+        result["roofline"]["step_traffic_gb"] = tj.get("step_traffic_gb")
+        result["roofline"]["step_algorithmic_gb"] = tj.get("step_algorithmic_gb")
+        result["roofline"]["step_traffic_by_class_gb"] = tj.get("step_traffic_by_class_gb")
+        result["roofline"]["traffic_measured_over_algorithmic"] = tj.get("measured_over_algorithmic")
     # whole-step fractions SURVEY.md 8(d) defines (Generator-only algorithmic work per audio-second over the step time)
-    audio_s = args.batch * args.seconds
+    audio_s = wl.B * args.seconds          # rank 0's shard: what the timed step of THIS rank synthesised (--global-batch)
     result["roofline"]["step_fma_fraction"] = 63.3e9 * audio_s / (result["ms_per_step"] * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     result["roofline"]["step_hbm_fraction"] = 391e6 * audio_s / (result["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
     # continuity with BENCH_r02 / r03 (`round2_launch_mix`): the same figure over the launches with more than 200 output
@@ -374,12 +387,29 @@ def vocoder_roofline(args, wl, result):
                 "the population BENCH_r02's roofline.frac was computed over; a subset of `roofline`'s launches"}
     # (round 4) the same population split by what the launch is: a conv of the path in its direct form, or the K = 1
     # channel product of a frequency-domain conv (per-bin weights, hsp_conv1d_args.w_bs) -- a launch class round 3 did not have
-    for name, sel in (("direct_convs", 0), ("channel_products", 1)):
-        part = [(fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, shp in rec if kind == "hsp_conv1d_mfma_f32" and shp[7] == sel]
+    # (round 5) the channel products run on their own kernel (cprod3_kernel, hsp_cprod3_f32: three real C x C products per
+    # bin, 6 C^2 flops per column instead of the block form's 8 C^2), so `roofline` -- conv1d_mfma_kernel -- now holds the
+    # direct convs only (unless HSP_FFT_PRODUCT=block); `mfma_gemm_population` is the union, round 4's population.
+    cp3 = [(fl, nb, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, _ in rec if kind == "hsp_cprod3_f32"]
+    for name, part in (("direct_convs", [(fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, shp in rec
+                                         if kind == "hsp_conv1d_mfma_f32" and shp[7] == 0]),
+                       ("channel_products", [(fl, e0.elapsed_time(e1)) for kind, fl, nb, e0, e1, shp in rec
+                                             if kind == "hsp_conv1d_mfma_f32" and shp[7] == 1] + [(f, m) for f, _, m in cp3])):
         if part:
             pms, pfl = sum(m for _, m in part), sum(f for f, _ in part)
             result["roofline"][name] = {"launches_per_step": len(part), "kernel_ms_per_step": pms, "achieved": pfl / (pms * 1e-3) / 1e12,
                                         "frac": pfl / (pms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    if cp3:
+        result["roofline"]["channel_products"].update({
+            "kernel": "cprod3_kernel (hsp_cprod3_f32)", "flops": "executed: 2 x 3 C^2 x Np x 64 bins per launch",
+            "algorithmic_mb_per_step": sum(b for _, b, _ in cp3) / 1e6,
+            "block_form_equivalent_tflops": sum(f for f, _, _ in cp3) * (4.0 / 3.0) / (sum(m for _, _, m in cp3) * 1e-3) / 1e12})
+        ums, ufl = tot_ms + sum(m for _, _, m in cp3), tot_fl + sum(f for f, _, _ in cp3)
+        result["roofline"]["mfma_gemm_population"] = {
+            "launches_per_step": len(mf) + len(cp3), "kernel_ms_per_step": ums, "achieved": ufl / (ums * 1e-3) / 1e12,
+            "frac": ufl / (ums * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "note": "conv1d_mfma_kernel + cprod3_kernel launches, executed flops: the population BENCH_r04's roofline.frac "
+                    "(0.573) was computed over, when the channel products still ran on conv1d_mfma_kernel"}
     # (round 4) the long AMP convs run in their frequency-domain form (forward DFT, ONE batched 1x1 product over the 64
     # bins on conv1d_mfma_kernel, inverse DFT: csrc/hsp_dftseg.hip).  `roofline` above counts the product launches with
     # the flops they EXECUTE; here the convs they stand for: the direct form's algorithmic flops over the time of all

@@ -305,7 +305,10 @@ int hsp_mha_f32(const hsp_mha_args* a, void* stream);
  *   y[b, m, i] = ((sum_c wt[m, c] o[b, c, i] + bias[m]) * mask[b, i]) * cscale[b, m] + res[b, m, i]
  * = scaled_dot_product_attention + out_proj + the residual add of the Mega-TTS2 PLM layer
  * (ttv_v1/transformer_mega.py:63-87,121-123: 4 heads x 69) and timm Attention's softmax(q k^T) v + proj followed by
- * `x + gate_msa * attn(.)` of a DiT block (modules.py:397,409: 2 heads x 96).  No masks inside the softmax, 4 <= Tk <= 256.
+ * `x + gate_msa * attn(.)` of a DiT block (modules.py:397,409: 2 heads x 96).  Any Tk >= 4 (up to 2^20): rows of up to 256
+ * keys take the one-pass form, longer ones stream the keys in groups with an online softmax (tested to 1 000 keys).  NO
+ * masks inside the softmax -- neither key / query masks nor a dense or causal attn_mask: a caller that needs one uses
+ * hsp_mha_f32 (mask_q / mask_k / mask_dense) and the projection as two launches.
  * q / k / v: element (b, c, t) at base + b * bs + c * cs + t (channel-major; a batch may sit side by side on the columns
  * of one [C][B * T] matrix: bs = T, cs = row pitch).  wt = the nn.Linear / 1x1-conv weight AS STORED, [M][H D] row-major
  * with row pitch wt_ld (M == H D).  y / res: element (b, m, i) at base + b * bs + m * cs + i * ts, so that the
@@ -522,6 +525,7 @@ typedef struct hsp_cprod3_args {
   const float* zeros;
   int64_t xf_bs, yf_bs; /* floats between bins, >= 2 C Np */
   int32_t bins, C, Np;
+  int32_t debug;        /* must be 0 (kernel decomposition switches of the tuning build, libhsp_tune.so) */
 } hsp_cprod3_args;
 int hsp_cprod3_f32(const hsp_cprod3_args* a, void* stream);
 int hsp_cprod3_supported(const hsp_cprod3_args* a);

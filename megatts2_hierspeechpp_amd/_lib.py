@@ -94,7 +94,7 @@ class Cprod3Args(C.Structure):
     """Mirror of ``hsp_cprod3_args``."""
     _fields_ = [
         ("xf", _fp), ("yf", _fp), ("w", _fp), ("zeros", _fp), ("xf_bs", C.c_int64), ("yf_bs", C.c_int64),
-        ("bins", C.c_int32), ("C", C.c_int32), ("Np", C.c_int32),
+        ("bins", C.c_int32), ("C", C.c_int32), ("Np", C.c_int32), ("debug", C.c_int32),
     ]
 
 

@@ -410,6 +410,10 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
                                              const int lane, const int nchunks, const int lkc, const int xvec) {
   constexpr int BM = C::BM;
   const int KC = P.kc;
+  // validate() refuses Cin < 1.  Said to the compiler as well: without it the "no chunk at all" exit it generates runs the
+  // epilogue on registers that the first fragment reads -- issued before the loop -- are still going to write
+  // (tools/check_isa.py reports exactly that path).
+  __builtin_assume(nchunks > 0);
   const int wave = wm * C::kWN + wn;               // only the VEC epilogue's staging slot uses it (full tiles)
   const int l32 = lane & 31, half = lane >> 5;
   const int mw = m0 + wm * (TM * 32);               // first packed row of this wave
@@ -1106,7 +1110,8 @@ int launch_one(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   // 8-utterance front group is 384 tiles -- two rounds of lone workgroups at 52 us, one round of pairs at ~40.
   const int64_t tiles = (int64_t)((a.M + C::BM - 1) / C::BM) * ((a.ncols + C::BN - 1) / C::BN) * a.B;
   // (same box: 42.4 -> 39.3 us per launch, step 81.05 -> 80.77 ms; beyond 512 tiles the deep chunk wins again: 67.8 vs 69.7)
-  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS || (tiles > 256 && tiles <= 512 && !HSP_DBG(a, 1 << 21));
+  // (tuning bit 1 << 26: the half-CU chunk for ANY launch of up to 512 tiles, so that launches of different streams can share a CU)
+  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS || ((tiles > 256 || HSP_DBG(a, 1 << 26)) && tiles <= 512 && !HSP_DBG(a, 1 << 21));
   int lkc = pick_lkc<C>(a, two_per_cu ? kLdsTarget : kMaxLdsBytes);
   if (lkc < 0) lkc = pick_lkc<C>(a, kMaxLdsBytes);
   if (lkc < 0) return HSP_EINVAL;

@@ -32,6 +32,9 @@ constexpr int CP_WS = 3 * CP_KC * CP_BM;          // floats of the weight slabs 
 constexpr int CP_XS = 2 * CP_KC * CP_BN;          // floats of the spectrum windows: [2][KC][BN]
 constexpr int CP_BUF = CP_WS + CP_XS;             // one half of the double buffer: 28 KB
 constexpr int CP_THREADS = 512;
+// tuning build only (hsp_cprod3_args.debug, refused by the release library): 1 producers stage chunk 0 only, 2 no MFMAs,
+// 16 no epilogue, 2048 no barriers, 4096 no narrow consumer for partial column tiles -- results are then wrong
+#define CP_BARRIER(a) do { if (!HSP_DBG(a, 2048)) lds_barrier(); } while (0)
 
 template <int OFF>
 __device__ __forceinline__ void cp_rd(float& dst, unsigned addr) {
@@ -39,35 +42,135 @@ __device__ __forceinline__ void cp_rd(float& dst, unsigned addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 
-// fragment set of one k-step (two input channels): A of the three matrices, Re / Im of the two column blocks
+// fragment set of one k-step (two input channels): A of the three matrices, Re / Im of the NB column blocks of the wave
+template <int NB>
 struct CpFrag {
-  float a[3], r[2], i[2];
+  float a[3], r[NB > 0 ? NB : 1], i[NB > 0 ? NB : 1];
 };
-template <int S>
-__device__ __forceinline__ void cp_issue(CpFrag& f, unsigned va, unsigned vb) {
+template <int S, int NB>
+__device__ __forceinline__ void cp_issue(CpFrag<NB>& f, unsigned va, unsigned vb) {
   constexpr int A0 = S * 2 * CP_BM * 4, B0 = S * 2 * CP_BN * 4;
   cp_rd<A0>(f.a[0], va);
   cp_rd<A0 + CP_KC * CP_BM * 4>(f.a[1], va);
   cp_rd<A0 + 2 * CP_KC * CP_BM * 4>(f.a[2], va);
   cp_rd<B0>(f.r[0], vb);
-  cp_rd<B0 + 128>(f.r[1], vb);
+  if constexpr (NB > 1) cp_rd<B0 + 128>(f.r[1], vb);
   cp_rd<B0 + CP_KC * CP_BN * 4>(f.i[0], vb);
-  cp_rd<B0 + CP_KC * CP_BN * 4 + 128>(f.i[1], vb);
+  if constexpr (NB > 1) cp_rd<B0 + CP_KC * CP_BN * 4 + 128>(f.i[1], vb);
 }
 // the set is valid behind the wait; re-defining its registers there gives every consumer a data dependency on the wait
 // (hsp_conv1d_mfma_kernel.h: wait_frags)
-__device__ __forceinline__ void cp_bind(CpFrag& f) {
+template <int NB>
+__device__ __forceinline__ void cp_bind(CpFrag<NB>& f) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(f.a[j]));
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NB; ++n) {
     asm volatile("" : "+v"(f.r[n]));
     asm volatile("" : "+v"(f.i[n]));
   }
 }
-__device__ __forceinline__ void cp_wait(CpFrag& f) {
+template <int NB>
+__device__ __forceinline__ void cp_wait(CpFrag<NB>& f) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   cp_bind(f);
+}
+
+// The consumer role of one wave: rows m0 + 32 wm ... of C, NB = 1 or 2 valid 32-column blocks from n0 + 64 wn.  A wave
+// whose second block lies wholly past Np (the last column tile of a bin: Np = 224 is 128 + 96) multiplies half as much;
+// the MFMA pipe it leaves idle goes to the other workgroup's wave on its SIMD.
+template <int NB>
+__device__ __forceinline__ void cp_consume(const hsp_cprod3_args& a, float* const lds, const int bin, const int m0, const int n0,
+                                           const int wm, const int wn, const int lane, const int nchunks) {
+  const int C = a.C, Np = a.Np;
+  const int l32 = lane & 31, half = lane >> 5;
+  f32x16 k1[NB], k2[NB], k3[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k1[n][r] = k2[n][r] = k3[n][r] = 0.0f;
+  const unsigned aA = lds_addr(lds + half * CP_BM + wm * 32 + l32);
+  const unsigned aB = lds_addr(lds + CP_WS + half * CP_BN + wn * 64 + l32);
+  CpFrag<NB> f0, f1;
+  auto mma = [&](CpFrag<NB>& f) __attribute__((always_inline)) {
+    if (HSP_DBG(a, 2)) return;
+    // Xr + Xi and Xi - Xr on the fragments: counted VALU instructions between the wait and the first MFMA
+    float s[NB], d[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      s[n] = f.r[n] + f.i[n];
+      d[n] = f.i[n] - f.r[n];
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      k1[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0], f.r[n], k1[n], 0, 0, 0);
+      k2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1], d[n], k2[n], 0, 0, 0);
+      k3[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[2], s[n], k3[n], 0, 0, 0);
+    }
+  };
+  CP_BARRIER(a);                                                // chunk 0 staged
+  unsigned va = aA, vb = aB;
+  cp_issue<0>(f0, va, vb);
+  for (int c = 0; c < nchunks; ++c) {
+    // eight k-steps, fully unrolled: the reads of step S + 1 go out behind the wait that retires step S's and BEFORE
+    // step S's MFMAs; the barrier that hands over chunk c + 1 sits between the last two MFMA groups of chunk c, and the
+    // first reads of chunk c + 1 go out behind it (hsp_conv1d_mfma_kernel.h: the fragment pipeline runs across chunks)
+    static_for<CP_KC / 2>([&](auto SS) __attribute__((always_inline)) {
+      constexpr int S = decltype(SS)::value;
+      CpFrag<NB>& cur = (S & 1) ? f1 : f0;
+      CpFrag<NB>& nxt = (S & 1) ? f0 : f1;
+      if constexpr (S + 1 < CP_KC / 2) {
+        cp_wait(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cp_issue<S + 1>(nxt, va, vb);
+      } else {
+        CP_BARRIER(a);                                          // (waits lgkmcnt(0)) chunk c + 1 is staged, chunk c's buffer is free
+        cp_wait(cur);
+        if (c + 1 < nchunks) {
+          const unsigned off = ((c + 1) & 1) ? (unsigned)(CP_BUF * 4) : 0u;
+          va = aA + off;
+          vb = aB + off;
+          __builtin_amdgcn_sched_barrier(0);
+          cp_issue<0>(nxt, va, vb);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  if (HSP_DBG(a, 16)) return;
+
+  // ---- epilogue: Yr = k1 - k3 -> row m, Yi = k1 + k2 -> row C + m; stores straight from the accumulator layout (one
+  // instruction = two rows x 128 B), uniform row pointer + one per-lane offset per column block
+  float* const yb = a.yf + (int64_t)bin * a.yf_bs;
+  const int lrow = m0 + wm * 32 + 4 * half;
+  const int col0 = n0 + wn * 64 + l32;
+  int voff[NB];
+  bool cok[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    voff[n] = lrow * Np + col0 + 32 * n;
+    cok[n] = col0 + 32 * n < Np;
+  }
+  const bool full = n0 + wn * 64 + 32 * NB <= Np;               // wave-uniform: every column of the wave's blocks exists
+  auto store = [&](auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    static_for<16>([&](auto rr) __attribute__((always_inline)) {
+      constexpr int r = decltype(rr)::value;
+      float* const yr = yb + (int64_t)HSP_ACC_ROW(r, 0) * Np;   // uniform
+      float* const yi = yr + (int64_t)C * Np;
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        if (!MASKED || cok[n]) {
+          yr[voff[n]] = k1[n][r] - k3[n][r];
+          yi[voff[n]] = k1[n][r] + k2[n][r];
+        }
+      }
+    });
+  };
+  if (full) store(std::false_type{});
+  else store(std::true_type{});
 }
 
 __global__ __launch_bounds__(CP_THREADS, 4) void cprod3_kernel(const hsp_cprod3_args a, const int n_mt, const int n_nt) {
@@ -81,13 +184,13 @@ __global__ __launch_bounds__(CP_THREADS, 4) void cprod3_kernel(const hsp_cprod3_
   const int nt = bid % n_nt, bin = bid / n_nt;
   const int m0 = mt * CP_BM, n0 = nt * CP_BN;
   const int nchunks = C / CP_KC;
-  const bool full = n0 + CP_BN <= Np;                           // workgroup-uniform: no column of the tile is past Np
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------------ producers
     // A DMA instruction moves 1 KB: four slab rows (64 floats each) or two window rows (128 floats).  A lane's byte
     // offset is computed once; the scalar unit walks the wave-uniform row base (hsp_conv1d_mfma_kernel.h: dma_w_fast).
     const int pw = wave - 4;
+    const bool full = n0 + CP_BN <= Np;                         // workgroup-uniform: no column of the tile is past Np
     const float* const wb = a.w + (int64_t)bin * 3 * C * C + m0;
     const float* const xb = a.xf + (int64_t)bin * a.xf_bs + n0;
     const unsigned wofs = 4u * (unsigned)((lane >> 4) * C + (lane & 15) * 4);
@@ -111,104 +214,27 @@ __global__ __launch_bounds__(CP_THREADS, 4) void cprod3_kernel(const hsp_cprod3_
     };
     stage(0, lds);
     wait_vm0();
-    lds_barrier();
+    CP_BARRIER(a);
     for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) {
+      if (c + 1 < nchunks && !HSP_DBG(a, 1)) {
         stage((c + 1) * CP_KC, lds + ((c + 1) & 1) * CP_BUF);
         wait_vm0();
       }
-      lds_barrier();
+      CP_BARRIER(a);
     }
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- consumers
   const int wm = wave >> 1, wn = wave & 1;
-  const int l32 = lane & 31, half = lane >> 5;
-  f32x16 k1[2], k2[2], k3[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) k1[n][r] = k2[n][r] = k3[n][r] = 0.0f;
-  const unsigned aA = lds_addr(lds + half * CP_BM + wm * 32 + l32);
-  const unsigned aB = lds_addr(lds + CP_WS + half * CP_BN + wn * 64 + l32);
-  CpFrag f0, f1;
-  auto mma = [&](CpFrag& f) __attribute__((always_inline)) {
-    // Xr + Xi and Xi - Xr on the fragments: counted VALU instructions between the wait and the first MFMA
-    float s[2], d[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      s[n] = f.r[n] + f.i[n];
-      d[n] = f.i[n] - f.r[n];
-    }
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      k1[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0], f.r[n], k1[n], 0, 0, 0);
-      k2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1], d[n], k2[n], 0, 0, 0);
-      k3[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[2], s[n], k3[n], 0, 0, 0);
-    }
-  };
-  lds_barrier();                                                // chunk 0 staged
-  unsigned va = aA, vb = aB;
-  cp_issue<0>(f0, va, vb);
-  for (int c = 0; c < nchunks; ++c) {
-    // eight k-steps, fully unrolled: the reads of step S + 1 go out behind the wait that retires step S's and BEFORE
-    // step S's MFMAs; the barrier that hands over chunk c + 1 sits between the last two MFMA groups of chunk c, and the
-    // first reads of chunk c + 1 go out behind it (hsp_conv1d_mfma_kernel.h: the fragment pipeline runs across chunks)
-    static_for<CP_KC / 2>([&](auto SS) __attribute__((always_inline)) {
-      constexpr int S = decltype(SS)::value;
-      CpFrag& cur = (S & 1) ? f1 : f0;
-      CpFrag& nxt = (S & 1) ? f0 : f1;
-      if constexpr (S + 1 < CP_KC / 2) {
-        cp_wait(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        cp_issue<S + 1>(nxt, va, vb);
-      } else {
-        lds_barrier();                                          // (waits lgkmcnt(0)) chunk c + 1 is staged, chunk c's buffer is free
-        cp_bind(cur);
-        if (c + 1 < nchunks) {
-          const unsigned off = ((c + 1) & 1) ? (unsigned)(CP_BUF * 4) : 0u;
-          va = aA + off;
-          vb = aB + off;
-          __builtin_amdgcn_sched_barrier(0);
-          cp_issue<0>(nxt, va, vb);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma(cur);
-      __builtin_amdgcn_sched_barrier(0);
-    });
+  const int left = Np - (n0 + wn * 64);                         // columns from this wave's first block to the end of the bin
+  if (left > 32 || HSP_DBG(a, 4096)) {
+    cp_consume<2>(a, lds, bin, m0, n0, wm, wn, lane, nchunks);
+  } else if (left > 0) {
+    cp_consume<1>(a, lds, bin, m0, n0, wm, wn, lane, nchunks);
+  } else {
+    for (int c = 0; c <= nchunks; ++c) CP_BARRIER(a);           // no column of this wave exists: keep the barrier count
   }
-
-  // ---- epilogue: Yr = k1 - k3 -> row m, Yi = k1 + k2 -> row C + m; stores straight from the accumulator layout (one
-  // instruction = two rows x 128 B), uniform row pointer + one per-lane offset per column block
-  float* const yb = a.yf + (int64_t)bin * a.yf_bs;
-  const int lrow = m0 + wm * 32 + 4 * half;
-  const int col0 = n0 + wn * 64 + l32;
-  int voff[2];
-  bool cok[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    voff[n] = lrow * Np + col0 + 32 * n;
-    cok[n] = col0 + 32 * n < Np;
-  }
-  auto store = [&](auto masked_tag) __attribute__((always_inline)) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-    static_for<16>([&](auto rr) __attribute__((always_inline)) {
-      constexpr int r = decltype(rr)::value;
-      float* const yr = yb + (int64_t)HSP_ACC_ROW(r, 0) * Np;   // uniform
-      float* const yi = yr + (int64_t)C * Np;
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        if (!MASKED || cok[n]) {
-          yr[voff[n]] = k1[n][r] - k3[n][r];
-          yi[voff[n]] = k1[n][r] + k2[n][r];
-        }
-      }
-    });
-  };
-  if (full) store(std::false_type{});
-  else store(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------- weight spectrum
@@ -271,6 +297,9 @@ __global__ __launch_bounds__(256) void wspec_kernel(const float* __restrict__ w,
 int cp_check(const hsp_cprod3_args& a) {
   if (!a.xf || !a.yf || !a.w || !a.zeros) return HSP_EINVAL;
   if (a.bins <= 0 || a.C <= 0 || a.Np <= 0) return HSP_EINVAL;
+#ifndef HSP_TUNING
+  if (a.debug) return HSP_EINVAL;
+#endif
   if (a.C % CP_BM || (a.Np & 3)) return HSP_EINVAL;             // whole row tiles, 16-B column groups
   if (a.xf_bs < (int64_t)2 * a.C * a.Np || a.yf_bs < (int64_t)2 * a.C * a.Np || (a.xf_bs & 3) || (a.yf_bs & 3)) return HSP_EINVAL;
   if ((reinterpret_cast<uintptr_t>(a.xf) | reinterpret_cast<uintptr_t>(a.w)) & 15) return HSP_EINVAL;

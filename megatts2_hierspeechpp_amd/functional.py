@@ -32,13 +32,8 @@ def sequence_mask(length: torch.Tensor, max_length: int) -> torch.Tensor:
 ACT_HOOK = None  # measurement hook (bench.py): hook(algorithmic_bytes, ev_start, ev_end) around every stand-alone activation
 
 
-ACT_SKIP = False  # tools/act_hidden_ab.py ONLY: the activation becomes the identity (wrong results) -- what is its launch worth?
-
-
 def act1d(x, ea, binv, filt, out=None):
     x = _c(x)
-    if ACT_SKIP:
-        return x
     B, Cc, T = x.shape
     out = _new_like(x) if out is None else out
     hook = ACT_HOOK

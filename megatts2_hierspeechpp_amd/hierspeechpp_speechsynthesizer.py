@@ -140,36 +140,43 @@ class AMPBlock1(nn.Module):
         """``before_last``: an event the current stream waits on before the last launch (the one
         that accumulates into the shared ``out`` of the stage)."""
         n = len(self.convs1)
-        fuse = self.convs1[0].cin <= FUSE_ACT_MAX_CHANNELS
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             last = i == n - 1
-            a1, a2 = self.activations[2 * i], self.activations[2 * i + 1]
-            kw = dict(res=x, out=out if last else None, accumulate=accumulate and last,
-                      post_scale=post_scale if last else 1.0)
-            if fuse:
-                xt = c1(x, act1d=a1)
-                if last and before_last is not None:
-                    torch.cuda.current_stream(x.device).wait_event(before_last)
-                x = c2(xt, act1d=a2, **kw)
-            else:
-                # a conv in its frequency-domain form applies its activation while the forward transform stages the
-                # input (hsp_dftseg_args.act_*): no launch, no act(x) in HBM; two such convs in a row also meet in one
-                # launch (inverse of c1 + a2 + forward of c2, hsp_dftseg_pair_f32): xt never in HBM either
-                if fft_wins(c1, x) and fft_wins(c2, x) and fft_act(x) and FFT_PAIR and c1.fft_pair_ok(c2, x):
-                    x = c1.forward_fft_pair(c2, x, act_first=a1, act_second=a2, before_inverse=before_last if last else None, **kw)
-                    continue
-                if fft_wins(c1, x):
-                    xt = c1.forward_fft(x, act1d=a1) if fft_act(x) else c1.forward_fft(a1(x))
-                else:
-                    xt = c1(a1(x))
-                if last and before_last is not None and not fft_wins(c2, xt):
-                    torch.cuda.current_stream(x.device).wait_event(before_last)
-                if fft_wins(c2, xt):
-                    x = c2.forward_fft(xt, act1d=a2, before_inverse=before_last if last else None, **kw) if fft_act(xt) \
-                        else c2.forward_fft(a2(xt), before_inverse=before_last if last else None, **kw)
-                else:
-                    x = c2(a2(xt), **kw)
+            x = amp_pair(c1, c2, self.activations[2 * i], self.activations[2 * i + 1], x,
+                         before_last=before_last if last else None, res=x, out=out if last else None,
+                         accumulate=accumulate and last, post_scale=post_scale if last else 1.0)
         return x
+
+
+def amp_pair(c1, c2, a1, a2, x, *, form=None, before_last=None, **kw):
+    """One iteration of AMPBlock1.forward (hierspeechpp_speechsynthesizer.py:380-384): c2(a2(c1(a1(x)))) with c2's epilogue
+    ``kw`` (res, out, accumulate, post_scale).  ``form`` None = the policy below picks per conv (fft_wins) and per pair
+    (fft_pair_ok); "direct" / "fft" / "pair" force one form -- tools/fftconv_table.py measures the policy against them.
+    ``before_last``: an event the stream waits on before the launch that touches ``out``."""
+    if c1.cin <= FUSE_ACT_MAX_CHANNELS and form is None:
+        xt = c1(x, act1d=a1)
+        if before_last is not None:
+            torch.cuda.current_stream(x.device).wait_event(before_last)
+        return c2(xt, act1d=a2, **kw)
+    # a conv in its frequency-domain form applies its activation while the forward transform stages the input
+    # (hsp_dftseg_args.act_*): no launch, no act(x) in HBM; two such convs in a row also meet in one launch (inverse of c1
+    # + a2 + forward of c2, hsp_dftseg_pair_f32): xt never in HBM either
+    w1 = fft_wins(c1, x) if form is None else form != "direct"
+    w2 = fft_wins(c2, x) if form is None else form != "direct"
+    if w1 and w2 and fft_act(x) and ((FFT_PAIR and form is None) or form == "pair") and c1.fft_pair_ok(c2, x):
+        return c1.forward_fft_pair(c2, x, act_first=a1, act_second=a2, before_inverse=before_last, **kw)
+    if form == "pair":
+        raise L.HspError("amp_pair(form='pair'): hsp_dftseg_pair_supported says no for this geometry")
+    if w1:
+        xt = c1.forward_fft(x, act1d=a1) if fft_act(x) else c1.forward_fft(a1(x))
+    else:
+        xt = c1(a1(x))
+    if before_last is not None and not w2:
+        torch.cuda.current_stream(x.device).wait_event(before_last)
+    if w2:
+        return c2.forward_fft(xt, act1d=a2, before_inverse=before_last, **kw) if fft_act(xt) \
+            else c2.forward_fft(a2(xt), before_inverse=before_last, **kw)
+    return c2(a2(xt), **kw)
 
 
 # Where the frequency-domain form of an AMP conv beats the direct MFMA conv: fft_eligible (by shape) and fft_min_cols (by
@@ -190,13 +197,17 @@ def fft_eligible(channels: int, k: int, dilation: int) -> bool:
 
 def fft_min_cols(channels: int, k: int) -> int:
     """Samples per channel (batch x length) from which the frequency-domain form wins: its product launch reads one
-    matrix set per bin (201 MB at 512 channels) and there are three launches, a floor that a single short utterance
-    does not amortise (profiles/r04_fftconv_batch.txt: 0.19 ms at 512 channels whatever the batch is, up to 8 x 4 s)."""
+    matrix set per bin (201 MB per conv at 512 channels) and there are three launches, a floor that a short single
+    utterance does not always amortise.  From profiles/r05_fftconv_dispatch_table.txt (504 cells: B 1 ... 64 x T 50 / 200 /
+    1000 x every (C, k, d) of the blocks, each AMP iteration as direct / frequency-domain / pair launch): with the
+    three-product channel mix (round 5) the form wins from far fewer samples than with round 4's block product -- k = 11 at
+    512 channels at ANY size (1.2-1.4 x on a single 1-s utterance), k = 7 there from 3 200; the dilation does not move
+    the thresholds."""
     if FFT_MIN_COLS is not None:
         return FFT_MIN_COLS
     if k >= 11:
-        return 6400 if channels >= 512 else 8000 if channels >= 256 else 32000 if channels >= 128 else 256000
-    return 6400 if channels >= 512 else 16000 if channels >= 256 else 128000
+        return 0 if channels >= 512 else 8000 if channels >= 256 else 32000 if channels >= 128 else 128000
+    return 3200 if channels >= 512 else 8000 if channels >= 256 else 64000
 
 
 # HSP_FFT_MIN_COLS=<n> (or the module attribute) replaces the measured thresholds above; 0 forces the form on every

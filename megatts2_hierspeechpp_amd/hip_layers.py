@@ -513,7 +513,7 @@ class Conv1d(_ConvBase):
         if self._wf_form == "three":
             pa = L.Cprod3Args()
             pa.xf, pa.yf, pa.w, pa.zeros = L.fptr(xf), L.fptr(yf), L.fptr(wf), L.fptr(_zeros(xf.device))
-            pa.xf_bs, pa.yf_bs, pa.bins, pa.C, pa.Np = xf.stride(0), yf.stride(0), 64, Cc, Np
+            pa.xf_bs, pa.yf_bs, pa.bins, pa.C, pa.Np, pa.debug = xf.stride(0), yf.stride(0), 64, Cc, Np, DEBUG_FLAGS
             hook = LAUNCH_HOOK
             if hook is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

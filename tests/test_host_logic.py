@@ -443,3 +443,34 @@ def test_three_product_weights_reproduce_the_complex_product():
     xr, xi = -E0, -O0
     k1, k2, k3 = 0.0 * xr, Wny @ (xi - xr), Wdc @ (xr + xi)
     assert np.allclose(k1 - k3, Wdc @ (E0 + O0)) and np.allclose(k1 + k2, Wny @ (E0 - O0))
+
+
+def test_isa_lint_finds_a_fragment_used_before_its_wait(tmp_path):
+    """tools/check_isa.py (make check-isa): an instruction that touches the destination of an inline-asm ds_read before the
+    s_waitcnt that validates it is reported; the same code with the wait in place, a read issued on the loop-continue side
+    of a scalar test only, and a partial lgkmcnt(N) wait are not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    head = "kern:\n"
+    rd = lambda reg, addr: f"\t;;#ASMSTART\n\tds_read_b32 {reg}, {addr} offset:0\n\t;;#ASMEND\n"
+    wait = lambda n: f"\t;;#ASMSTART\n\ts_waitcnt lgkmcnt({n})\n\t;;#ASMEND\n"
+    cases = {
+        "copy_before_wait": (head + rd("v10", "v1") + "\tv_mov_b32_e32 v20, v10\n" + wait(0) + "\ts_endpgm\n", 1),
+        "spill_before_wait": (head + rd("v10", "v1") + "\tscratch_store_dword off, v10, s0\n" + wait(0) + "\ts_endpgm\n", 1),
+        "mfma_before_wait": (head + rd("v10", "v1") + "\tv_mfma_f32_32x32x2_f32 v[20:35], v10, v2, v[20:35]\n" + wait(0)
+                             + "\ts_endpgm\n", 1),
+        "clean": (head + rd("v10", "v1") + "\tv_add_f32_e32 v3, v4, v5\n" + wait(0) + "\tv_mov_b32_e32 v20, v10\n\ts_endpgm\n", 0),
+        "partial_wait": (head + rd("v10", "v1") + rd("v11", "v1") + wait(1) + "\tv_mov_b32_e32 v20, v10\n" + wait(0)
+                         + "\tv_mov_b32_e32 v21, v11\n\ts_endpgm\n", 0),
+        "partial_wait_too_early": (head + rd("v10", "v1") + rd("v11", "v1") + wait(1) + "\tv_mov_b32_e32 v21, v11\n" + wait(0)
+                                   + "\ts_endpgm\n", 1),
+        # the consumer loops: the next chunk's first reads sit behind `c + 1 < nchunks`, the same scalars as the loop exit
+        "loop_exit": (head + ".LBB0_1:\n\ts_add_i32 s8, s8, 1\n\ts_cmp_lt_i32 s8, s56\n\ts_cbranch_scc0 .LBB0_2\n"
+                      + rd("v10", "v1") + ".LBB0_2:\n\tv_add_f32_e32 v3, v4, v5\n\ts_cmp_eq_u32 s8, s56\n\ts_cbranch_scc1 .LBB0_3\n"
+                      + wait(0) + "\tv_mov_b32_e32 v20, v10\n\ts_branch .LBB0_1\n.LBB0_3:\n\tv_mov_b32_e32 v10, v7\n\ts_endpgm\n", 0),
+    }
+    for name, (text, want) in cases.items():
+        f = tmp_path / f"{name}.s"
+        f.write_text(text)
+        findings, n = check_isa.lint(str(f))
+        assert n >= 1 and len(findings) == want, (name, findings)

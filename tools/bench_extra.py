@@ -55,6 +55,8 @@ def conv_entry_profile(fn):
             plan = (C.c_int32 * 4)()
             L.check(L.lib().hsp_conv1d_mfma_plan(C.byref(la), C.byref(plan)), "hsp_conv1d_mfma_plan")
             kind = "conv1d_mfma_kernel" if plan[2] > 0 else ("rgemm_kernel" if plan[2] == -1 else "bgemm_kernel")
+        if kind == "hsp_cprod3_f32":
+            kind = "cprod3_kernel"
         if kind != "hsp_fftconv":          # the whole-conv record of a frequency-domain conv spans its three launches
             rec.append((kind, fl, nb, e0, e1))
 

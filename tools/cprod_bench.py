@@ -55,6 +55,9 @@ for st in a.stages:
     lay.ensure_wf()
     fl = 2.0 * 64 * (3 if lay._wf_form == "three" else 4) * C_ * C_ * da.Np   # executed: three C x C products or the 2C x 2C block
     line = f"{C_:4d} {L_:6d} {a.k:2d} {a.d} {da.Np:6d} |"
+    for _ in range(200):                       # ~60 ms of the launch itself: clocks and caches as inside a step
+        lay._fft_product(xf)
+    torch.cuda.synchronize()
     for dbg in a.debug:
         hip_layers.DEBUG_FLAGS = dbg
         t = timed(lambda: lay._fft_product(xf))

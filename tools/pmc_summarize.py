@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r04_traffic.json.
+"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/r05_traffic.json.
 bench.py quotes `roofline.traffic` from that file ONLY when the kernel-source hash, the workload size and the launch mix
 recorded here equal the run's own (the library is identified by the hash of its kernel sources).
 
-    python tools/pmc_summarize.py gpurun_out profiles/r04_traffic.json [bench line of the same build]
+    python tools/pmc_summarize.py gpurun_out profiles/r05_traffic.json [bench line of the same build]
 
 FETCH_SIZE on gfx950 under-reports wide coalesced reads (exactly 1/2 for 16-B-per-lane streams, MI355X_MICROARCH.md);
 three figures are given for every kernel class: raw (as counted), x2 (the guide's literal correction) and calibrated
@@ -17,8 +17,8 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = ["conv1d_mfma_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "dftseg_fwd_kernel", "dftseg_inv_kernel",
-           "act1d_seg_kernel", "act1d_kernel",
+CLASSES = ["conv1d_mfma_kernel", "cprod3_kernel", "wspec_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel",
+           "dftseg_fwd_kernel", "dftseg_inv_kernel", "dftseg_pair_kernel", "act1d_seg_kernel", "act1d_kernel",
            "mha_mfma_kernel", "mha_tok_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel"]
 B, T = 32, 200
 STEPS = 2  # bench.py --steps 1 --warmup 0 --no-graph executes the pre-capture step + 1
@@ -79,10 +79,30 @@ res = {
     "conv1d_mfma_bytes_per_step": three(conv),
     "act1d_seg_bytes_per_step": three(act),
 }
-for name in ("rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "dftseg_fwd_kernel", "dftseg_inv_kernel"):
+for name in ("cprod3_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "dftseg_fwd_kernel", "dftseg_inv_kernel",
+             "dftseg_pair_kernel"):
     if name in out:
         res[name + "_bytes_per_step"] = three(out[name])
+        res[name + "_launches_per_step"] = out[name]["launches"] // STEPS
+# (round 5) the whole step: calibrated bytes of every class that runs once per step -- the weight
+# packing of finalize() (copy kernels in `other`) and the once-per-process derivation of the per-bin matrices
+# (wspec_kernel) are NOT per-step traffic and stay out -- against SURVEY.md 8(d)'s algorithmic bytes of the full infer
+# path (405 MB per audio-second).  Per class: measured over algorithmic where the bench line of the same build carries the
+# algorithmic figure (the direct convs, the channel products, the stand-alone activation).
+line = json.loads(open(bench_line).read().strip().splitlines()[-1])
+rf = line.get("roofline", {})
+per_step = {k: three(v)["calibrated"] for k, v in out.items() if k not in ("other", "wspec_kernel")}
+res["step_traffic_gb"] = sum(per_step.values()) / 1e9
+res["step_traffic_by_class_gb"] = {k: v / 1e9 for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
+res["step_algorithmic_gb"] = 405e6 * B * (T / 50.0) / 1e9
+res["step_traffic_over_algorithmic"] = res["step_traffic_gb"] / res["step_algorithmic_gb"]
+res["not_per_step_gb"] = {k: three(out[k])["calibrated"] * STEPS / 1e9 for k in ("other", "wspec_kernel") if k in out}
+alg = {"conv1d_mfma_kernel": rf.get("algorithmic_mb_per_step"), "act1d_seg_kernel": ra["algorithmic_mb_per_step"],
+       "cprod3_kernel": rf.get("channel_products", {}).get("algorithmic_mb_per_step")}
+res["measured_over_algorithmic"] = {k: per_step[k] / (v * 1e6) for k, v in alg.items() if v and k in per_step}
 json.dump(res, open(dst, "w"), indent=1)
 print({k: res[k] for k in ("kernel_source_sha16", "fetch_factor", "write_check", "conv1d_mfma_launches_per_step", "act1d_launches_per_step")})
 print("conv1d_mfma GB/step", {k: round(v / 1e9, 2) for k, v in res["conv1d_mfma_bytes_per_step"].items()})
 print("act1d_seg GB/step", {k: round(v / 1e9, 2) for k, v in res["act1d_seg_bytes_per_step"].items()})
+print("step GB", round(res["step_traffic_gb"], 1), "algorithmic", round(res["step_algorithmic_gb"], 1), {k: round(v, 2) for k, v in res["step_traffic_by_class_gb"].items()})
+print("measured / algorithmic", {k: round(v, 2) for k, v in res["measured_over_algorithmic"].items()})
