@@ -206,7 +206,9 @@ def test_bench_control_flow_world8_cpu_stand_in(global_batch):
     lines = [r for _, r, _ in res]
     assert lines[0] is not None and all(ln is None for ln in lines[1:])     # only rank 0 reports
     line = lines[0]
-    assert line["n_gpus"] == 8 and line["rccl_world"] == 8 and line["backend"] == "gloo" and line["scaling"] == "weak"
+    # a fixed --global-batch is a strong-scaling run (the total work does not grow with the rank count); batch x gpus is weak
+    assert line["n_gpus"] == 8 and line["rccl_world"] == 8 and line["backend"] == "gloo"
+    assert line["scaling"] == ("weak" if global_batch is None else "strong")
     assert line["config"]["shard_of_rank0"] == [0, 32] and line["config"]["global_batch"] == total
     assert line["broadcast_ms"] > 0 and line["pack_ms"] > 0
     assert abs(line["value"] - total * 1000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
