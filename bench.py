@@ -582,6 +582,8 @@ def main(argv=None):
                                     for k, v in models.state_dict().items()})
             models.finalize(torch_device())
             extra["tts_b16"] = bench_extra.tts_b16(torch_device(), steps=3, models=models)
+            _progress("extra_configs: full TTS, two batches of 16 in flight")
+            extra["tts_2x16"] = bench_extra.tts_2x16(torch_device(), steps=3, models=models)
             _progress("extra_configs: full TTS, batch 1")
             extra["tts_b1"] = bench_extra.tts_b1(torch_device(), steps=3, models=models)
             result["extra_configs"] = extra

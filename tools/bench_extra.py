@@ -254,6 +254,20 @@ def tts_b1(dev, steps=3, models=None):
     return out
 
 
+def tts_2x16(dev, steps=3, models=None):
+    """Two 16-utterance TTS batches in flight, as ONE 32-row pass.  The greedy PLM loop is bound by
+    launch floors -- its per-step time does not depend on the step index or (much) on the row count
+    (profiles/r05_plm_step_curve.txt: 418 us per step at 16 rows, 391 at 32) -- so a second batch rides along for 27 ms instead
+    of 70, and the back half runs at the vocoder's 32-utterance rate.  What does NOT work is hiding the loop of batch i + 1
+    under the vocoder of batch i on a CU-masked stream (hipExtStreamCreateWithCUMask; profiles/r05_plm_overlap_probe.json):
+    the loop's launches are hundreds of workgroups wide, on 64 CUs it takes 243 ms instead of 70.  `ms_per_batch_of_16` is
+    the throughput figure; the latency of a single batch stays tts_b16's."""
+    out = tts_b16(dev, steps=steps, warmup=1, batch=32, models=models)
+    out["metric"] = "16kHz audio samples/sec, full inference_plm.py text->wav, two batches of 16 in flight as one 32-row pass"
+    out["ms_per_batch_of_16"] = out["ms_per_step"] / 2.0
+    return out
+
+
 def vocoder_b1_1s(dev, steps=20, net=None, frames=50):
     """BASELINE.json configs[0] (the reference's own CPU-runnable case: vocoder-only infer(), 1 utterance x 1 s) on
     the GPU: the latency of one small request, hipGraph replay.  bench.py's cpu_baseline times the same case on the
