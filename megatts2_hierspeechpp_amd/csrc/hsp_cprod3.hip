@@ -22,6 +22,9 @@
 // [16][64] weight slabs and two [16][128] spectrum windows, 28 KB -- by LDS-DMA into the other half of a double buffer.
 // The chunk depth is a compile-time constant, so every fragment address of a chunk is the lane's base plus an
 // immediate: no address arithmetic between the MFMAs.
+// Measured and not kept (same-box A/B of the 32 x 4 s step, profiles/r05_ab_cprod3_waveshape.json): consumer waves of
+// 64 rows x 32 columns instead of 32 x 64 -- two VALU instructions per six MFMAs instead of four, but eight fragment reads
+// instead of seven and every wave fetching all of the tile's A fragments: 58.96 against 58.72 ms per step.
 #include "hsp_conv1d_mfma_kernel.h"
 
 namespace {
