@@ -36,7 +36,8 @@ constexpr int CP_XS = 2 * CP_KC * CP_BN;          // floats of the spectrum wind
 constexpr int CP_BUF = CP_WS + CP_XS;             // one half of the double buffer: 28 KB
 constexpr int CP_THREADS = 512;
 // tuning build only (hsp_cprod3_args.debug, refused by the release library): 1 producers stage chunk 0 only, 2 no MFMAs,
-// 16 no epilogue, 2048 no barriers, 4096 no narrow consumer for partial column tiles -- results are then wrong
+// 16 no epilogue, 2048 no barriers, 4096 no narrow consumer for partial column tiles, 8192 no fragment sums, 16384 the plain block order -- results are
+// then wrong
 #define CP_BARRIER(a) do { if (!HSP_DBG(a, 2048)) lds_barrier(); } while (0)
 
 template <int OFF>
@@ -101,8 +102,8 @@ __device__ __forceinline__ void cp_consume(const hsp_cprod3_args& a, float* cons
     float s[NB], d[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      s[n] = f.r[n] + f.i[n];
-      d[n] = f.i[n] - f.r[n];
+      s[n] = HSP_DBG(a, 8192) ? f.i[n] : f.r[n] + f.i[n];       // (tuning bit 8192: no VALU between the MFMAs)
+      d[n] = HSP_DBG(a, 8192) ? f.i[n] : f.i[n] - f.r[n];
     }
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -181,10 +182,25 @@ __global__ __launch_bounds__(CP_THREADS, 4) void cprod3_kernel(const hsp_cprod3_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int C = a.C, Np = a.Np;
-  int bid = blockIdx.x;
-  const int mt = bid % n_mt;
-  bid /= n_mt;
-  const int nt = bid % n_nt, bin = bid / n_nt;
+  // Block order: every tile of a bin on ONE XCD (blocks b and b + 8 share an XCD -- observed dispatch order, speed only),
+  // row tiles fastest.  The n_mt row tiles of a column window then run side by side behind the same L2 and fetch the
+  // window once between them, and so do the column tiles of a weight slab: PMC traffic of the launches fell from 1.9 x to
+  // ~1.2 x their algorithmic bytes (profiles/r05_traffic.json).  With the plain order (row tile = blockIdx % n_mt) the
+  // row tiles of a window sat on n_mt DIFFERENT XCDs, each pulling its own copy from the Infinity Cache / HBM.
+  int mt, nt, bin;
+  {
+    const int bid = blockIdx.x, T = n_mt * n_nt;
+    if ((a.bins & 7) == 0 && !HSP_DBG(a, 16384)) {
+      const int q = bid >> 3, t = q % T;
+      bin = (q / T) * 8 + (bid & 7);
+      mt = t % n_mt;
+      nt = t / n_mt;
+    } else {
+      mt = bid % n_mt;
+      nt = (bid / n_mt) % n_nt;
+      bin = bid / T;
+    }
+  }
   const int m0 = mt * CP_BM, n0 = nt * CP_BN;
   const int nchunks = C / CP_KC;
 

@@ -78,11 +78,11 @@ def conv_entry_profile(fn):
 
 def _pmc_traffic(workload, kind, launches):
     """HBM bytes per launch of `kind` from the committed PMC profile of this workload's dominant stage
-    (profiles/r04_traffic_extra.json, tools/pmc_traffic_extra.sh), or (None, reason)."""
+    (profiles/r05_traffic_extra.json, tools/pmc_traffic_extra.sh), or (None, reason)."""
     import json
-    path = os.path.join(ROOT, "profiles", "r04_traffic_extra.json")
+    path = os.path.join(ROOT, "profiles", "r05_traffic_extra.json")
     if workload is None or not os.path.exists(path):
-        return None, "no profiles/r04_traffic_extra.json"
+        return None, "no profiles/r05_traffic_extra.json"
     from megatts2_hierspeechpp_amd.build import source_id
     tj = json.load(open(path))
     if tj.get("kernel_source_sha16") != source_id():

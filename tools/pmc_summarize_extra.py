@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold tools/pmc_traffic_extra.sh's passes into profiles/r04_traffic_extra.json (keyed by the kernel-source hash):
+"""Fold tools/pmc_traffic_extra.sh's passes into profiles/r05_traffic_extra.json (keyed by the kernel-source hash):
 per workload and kernel class the launches and the FETCH_SIZE / WRITE_SIZE KB of ONE pass (the script runs two).
 tools/bench_extra.py quotes `roofline.traffic` of extra_configs from it when the hash matches."""
 import csv
@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from megatts2_hierspeechpp_amd.build import source_id  # noqa: E402
 
-CLASSES = ["conv1d_mfma_kernel", "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "act1d_seg_kernel", "act1d_kernel",
+CLASSES = ["conv1d_mfma_kernel", "cprod3_kernel", "wspec_kernel", "dftseg_fwd_kernel", "dftseg_inv_kernel", "dftseg_pair_kernel",
+           "rgemm_kernel", "bgemm_kernel", "mha_proj_kernel", "act1d_seg_kernel", "act1d_kernel",
            "mha_tok_kernel", "mha_mfma_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel",
            "linear_interp", "plm_embed", "argmax"]
 PASSES = 2
@@ -28,7 +29,7 @@ def cls(name):
 
 res = {"kernel_source_sha16": source_id(), "passes_in_run": PASSES,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_extra.py; KB per ONE pass of the stage. "
-               "FETCH_SIZE under-reports 16-B-per-lane streams by the factor calibrated in r04_traffic.json (conv / LDS-DMA token "
+               "FETCH_SIZE under-reports 16-B-per-lane streams by the factor calibrated in r05_traffic.json (conv / LDS-DMA token "
                "GEMM); the register-path GEMM reads 4 B per lane, where round 1 measured 0.90 of the true bytes."}
 for w in ("tts", "sr48"):
     out = {}

@@ -1,6 +1,6 @@
 # PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the dominant stage of extra_configs.tts_b16 and sr48_b32:
 #     bash tools/pmc_traffic_extra.sh        then, in the build container:
-#     python tools/pmc_summarize_extra.py gpurun_out profiles/r04_traffic_extra.json
+#     python tools/pmc_summarize_extra.py gpurun_out profiles/r05_traffic_extra.json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for w in tts sr48; do
