@@ -1,11 +1,18 @@
-# round 5 final measurements: rocprof kernel stats of the serialised eager step + its bench line, PMC traffic passes, the
-# dispatch table of the conv forms under the final policy, the driver-format bench line
+# round 5 final measurements (one gpurun call): the whole GPU test suite + smoke(), rocprof kernel stats of the serialised
+# eager step + its bench line, PMC traffic passes (vocoder step; TTS / SR48 stages), the dispatch table of the conv forms
+# under the final policy, the driver-format bench line
 set -x
 R=$GRAFT_REPO_ROOT
 cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r05_t_all.log 2>&1
+tail -3 gpurun_out/r05_t_all.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_smoke.log 2>&1; tail -2 gpurun_out/r05_smoke.log
 bash tools/profile_final.sh && cd $R &&
 bash tools/pmc_traffic.sh && cd $R &&
+bash tools/pmc_traffic_extra.sh && cd $R &&
 python bench.py > gpurun_out/r05_bench_final.json 2> gpurun_out/r05_bench_final.err
-tail -c 400 gpurun_out/r05_bench_final.json
+tail -c 300 gpurun_out/r05_bench_final.json
 timeout -k 10 900 python tools/fftconv_table.py > gpurun_out/r05_fftconv_dispatch_table.txt 2> gpurun_out/r05_fftconv_dispatch_table.err
-tail -8 gpurun_out/r05_fftconv_dispatch_table.txt
+tail -6 gpurun_out/r05_fftconv_dispatch_table.txt
+python bench.py --dump-launches gpurun_out/r05_launch_table_final.txt --no-extra --no-cpu-baseline > gpurun_out/r05_bench_second.json 2>/dev/null
+head -30 gpurun_out/r05_launch_table_final.txt
