@@ -230,8 +230,10 @@ def fft_wins(conv, x) -> bool:
     ok = conv.__dict__.setdefault("_fft_ok", {})
     sup = ok.get((B, Lx))
     if sup is None:
+        if len(ok) >= 1024:          # a long-running process with ragged batches: the cache is a convenience, not a log
+            ok.clear()
         sup = ok[(B, Lx)] = conv.fft_supported(B, Lx)
-    if sup and conv._wf is None and torch.cuda.is_current_stream_capturing():
+    if sup and (conv._wf is None or conv._wf_form != conv.fft_form()) and torch.cuda.is_current_stream_capturing():
         global _WARNED_CAPTURE
         if not _WARNED_CAPTURE:
             _WARNED_CAPTURE = True

@@ -412,7 +412,7 @@ class Conv1d(_ConvBase):
         """The per-bin matrices of this conv's channel product, derived on the device from the packed taps (``_w``:
         [k][C][M]) in float64 and rounded once: [64][3][C][C] = (a + b, a, b) of conj(W) = a + i b for hsp_cprod3_f32, or
         round 4's [64][2C][2C] block matrices.  Deterministic: every rank derives the same bits from the same taps."""
-        if self._wf is not None:
+        if self._wf is not None and self._wf_form == self.fft_form():
             return self._wf
         self._require_ready()
         if torch.cuda.is_current_stream_capturing():
