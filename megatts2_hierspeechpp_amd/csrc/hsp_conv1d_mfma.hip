@@ -85,7 +85,21 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   if (!gated && a.debug & 8192) return hsp_conv_tile_M64P(a, epi, act, s, plan_out);
 #endif
   if (short_seq) {
-    if (gated) return hsp_conv_tile_S64G(a, epi, act, s, plan_out);
+    if (gated) {
+      // (round 5) a launch of a few 64 x 128 tiles is bound by ONE tile's MFMA chain per SIMD: 64 x 64 tiles whose
+      // chunk's K range is split between two wave pairs put twice the CUs on half the chain each (one WN layer of H = 192
+      // at 8 x 200 frames: 57.9 -> 40.3 us, at 1 x 200: 56.3 -> 39.0).  Only up to 48 such tiles (a request of up to four
+      // utterances): in the 32-utterance step the four batch groups of the front part run on four streams and fill the idle
+      // CUs with each other's launches -- there the wider footprint LOSES (same box: 57.5-57.6 -> 57.8 ms per step with
+      // the split tile on the 96-tile in-layers, profiles/r05_ab_s64g2*.json).  Tuning bits: 1 << 27 never, 1 << 28 up to
+      // 512 tiles.
+      const int64_t t128 = (int64_t)((a.M + 63) / 64) * ((a.ncols + 127) / 128) * a.B;
+      if ((t128 <= 48 || (HSP_DBG(a, 1 << 28) && t128 <= 512)) && !HSP_DBG(a, 1 << 27)) {
+        const int e = hsp_conv_tile_S64G2(a, epi, act, s, plan_out);
+        if (e != HSP_EINVAL) return e;
+      }
+      return hsp_conv_tile_S64G(a, epi, act, s, plan_out);
+    }
     if (a.M > 32) return hsp_conv_tile_S64(a, epi, act, s, plan_out);
     return hsp_conv_tile_S32(a, epi, act, s, plan_out);
   }

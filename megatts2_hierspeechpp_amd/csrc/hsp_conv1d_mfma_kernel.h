@@ -61,15 +61,20 @@ enum {
 
 namespace hspconv {
 
-template <int WM, int WN, int TM, int TN, int NPW_, int MINW_, int XSLACK_ = 64>
+template <int WM, int WN, int TM, int TN, int NPW_, int MINW_, int XSLACK_ = 64, int KS_ = 1>
 struct Cfg {
-  static constexpr int NCW = WM * WN;              // consumer waves (4, or 8 = two per SIMD)
+  // KS_ > 1 (round 5): the K range of every chunk is split between KS_ groups of WM x WN consumer waves; their partial
+  // sums meet in LDS behind the loop and group 0 runs the epilogue.  A short-sequence launch with fewer tiles than the chip
+  // has CUs is bound by ONE tile's MFMA chain per SIMD; halving the tile and splitting its K range puts the same four SIMDs
+  // of twice as many CUs on half the chain each (S64G2 below).
+  static constexpr int kKS = KS_;
+  static constexpr int NCW = WM * WN * KS_;        // consumer waves (4, or 8 = two per SIMD)
   static constexpr int kWM = WM, kWN = WN, kTM = TM, kTN = TN;
   static constexpr int BM = WM * TM * 32;
   static constexpr int BN = WN * TN * 32;
   static constexpr int NPW = NPW_;                 // producer waves
   static constexpr int NPT = NPW_ * 64;            // producer threads
-  static constexpr int THREADS = 64 * (WM * WN + NPW_);
+  static constexpr int THREADS = 64 * (WM * WN * KS_ + NPW_);
   static constexpr int MINW = MINW_;               // waves per SIMD the register allocation must allow
   // LDS row pitch of the input window, a compile-time constant so that the consumer loop can reach the next
   // channel pair through ds_read immediates: BN columns + halo (K-1)*dil + 3 (the 16-B window DMA starts at the
@@ -407,7 +412,8 @@ struct Prod {
 template <class C, int EPI, bool ACT, int TM, int TN>
 __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const LdsPlan& P, float* const lds, const int b,
                                              const int m0, const int t0, const int p0, const int wm, const int wn,
-                                             const int lane, const int nchunks, const int lkc, const int xvec) {
+                                             const int lane, const int nchunks, const int lkc, const int xvec,
+                                             const int ks = 0) {
   constexpr int BM = C::BM;
   const int KC = P.kc;
   // validate() refuses Cin < 1.  Said to the compiler as well: without it the "no chunk at all" exit it generates runs the
@@ -420,6 +426,10 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
   const int tw = t0 + wn * (TN * 32) + l32;         // this lane's column in block n = 0
   f32x16 acc[TM][TN];
 
+  // (a plain-row tile with a K split -- 64 x 64, two groups of four waves -- was built and measured in round 5: single
+  // requests 7.70 / 9.09 ms with the gated split tile alone, 7.68 / 9.11 with both; not kept, and with it went the
+  // accumulator-init handling a second K group needs: it would have to start from zero)
+  static_assert(C::kKS == 1 || EPI != HSP_EPI_INIT, "a K split with the accumulator-init epilogue would add the residual once per group");
   if constexpr (EPI == HSP_EPI_INIT) {
     // The accumulators START at bias + cbias + residual (+ the running sum of `accumulate`), loaded in
     // the MFMA C layout while the producers' first chunk is still in flight: the loads' latency hides
@@ -551,7 +561,9 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
 
   const int wlane = half * BM + wm * (TM * 32) + l32;
   const int xlane = half * P.xwp + wn * (TN * 32) + l32 + (xvec ? (p0 & 3) : 0);
-  const int nsteps = (a.K * KC) >> 1;  // even: KC >= 4, so a tap has an even number of channel pairs
+  // steps of a chunk (even: KC >= 4, so a tap has an even number of channel pairs); with a K split this group's share,
+  // [ks * nsteps, (ks + 1) * nsteps) of them (pick_lkc: the share is even, so a trip never straddles a tap)
+  const int nsteps = ((a.K * KC) >> 1) / C::kKS;
 
   HSP_BARRIER(a);  // chunk 0 staged
   // k-steps ordered tap outer, channel pair inner.  The weight slab is [tap][channel][row], so the A side is
@@ -584,7 +596,15 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
     // chunk).  Barrier count is unchanged: one before the loop, one per chunk.
     unsigned aA = lds_addr(lds + wlane);                 // per-lane LDS byte addresses of the chunk's buffers
     unsigned aB = lds_addr(lds + P.xa_off + xlane);
-    unsigned va = aA, vb = aB;
+    // where this K group's share of a chunk starts: step s0 = tap s0 / (KC / 2), channel pair s0 % (KC / 2)
+    int offA0 = 0, pairB0 = 0, tapoff0 = 0;
+    if constexpr (C::kKS > 1) {
+      const int s0 = ks * nsteps;
+      offA0 = s0 * kStepA;
+      pairB0 = (s0 & ((KC >> 1) - 1)) * rowB;
+      tapoff0 = (s0 >> (lkc - 1)) * tapB;
+    }
+    unsigned va = aA + (unsigned)offA0, vb = aB + (unsigned)(pairB0 + tapoff0);
     const bool run = !HSP_DBG(a, 2);
     if (run) {
       ds_read_frags<TM>(fa0, va);
@@ -595,7 +615,7 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
         HSP_BARRIER(a);
         continue;
       }
-      int offA = 0, pairB = 0, tapoff = 0;  // scalar byte offsets of the current trip
+      int offA = offA0, pairB = pairB0, tapoff = tapoff0;  // scalar byte offsets of the current trip
       // The hazard recogniser wants one COUNTED instruction between the re-definition of the fragments in wait_frags
       // and the first MFMA that reads them, and it does not count inline asm.  So the scalar walk of a trip sits in its
       // first slot, followed by the one scalar add hipcc emits itself (window offset = pair + tap), and the two VALU
@@ -646,8 +666,8 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
         const int nb = (c + 1) & 1;
         aA = lds_addr(lds + nb * P.ws_sz + wlane);
         aB = lds_addr(lds + P.xa_off + nb * P.xa_sz + xlane);
-        va = aA;
-        vb = aB;
+        va = aA + (unsigned)offA0;
+        vb = aB + (unsigned)(pairB0 + tapoff0);
         __builtin_amdgcn_sched_barrier(0);
         ds_read_frags<TM>(fa0, va);                // chunk c+1, step 0
         ds_read_frags<TN>(fb0, vb);
@@ -656,6 +676,39 @@ __device__ __forceinline__ void conv_consume(const hsp_conv1d_args& a, const Lds
       mma_set(fa1, fb1);                           // last step of chunk c, over the barrier's wake-up and the new reads
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+
+  if constexpr (C::kKS > 1) {
+    // The K groups' partial sums meet in LDS: the chunk buffers are free behind the loop's last barrier (every consumer
+    // retired its fragment reads there), the producers have left, so the barrier below counts the consumer waves only.
+    static_assert(C::kKS == 2, "one partner group per wave");
+    // (behind the VEC epilogue's per-wave staging slots: a group-0 wave that has finished adding may already be
+    // transposing its tile there while its neighbour still reads its partner's partial sums)
+    float* const red = lds + C::kWM * C::kWN * (32 * 36) + (wm * C::kWN + wn) * (TM * TN * 16 * 64) + lane;
+    if (ks > 0) {
+      static_for<TM>([&](auto ii) __attribute__((always_inline)) {
+        constexpr int i = decltype(ii)::value;
+        static_for<TN>([&](auto nn) __attribute__((always_inline)) {
+          constexpr int n = decltype(nn)::value;
+          static_for<16>([&](auto rr) __attribute__((always_inline)) {
+            constexpr int r = decltype(rr)::value;
+            red[((i * TN + n) * 16 + r) * 64] = acc[i][n][r];
+          });
+        });
+      });
+    }
+    lds_barrier();
+    if (ks > 0) return;
+    static_for<TM>([&](auto ii) __attribute__((always_inline)) {
+      constexpr int i = decltype(ii)::value;
+      static_for<TN>([&](auto nn) __attribute__((always_inline)) {
+        constexpr int n = decltype(nn)::value;
+        static_for<16>([&](auto rr) __attribute__((always_inline)) {
+          constexpr int r = decltype(rr)::value;
+          acc[i][n][r] += red[((i * TN + n) * 16 + r) * 64];
+        });
+      });
+    });
   }
 
   // ---- epilogue.  static_for keeps every accumulator index a compile-time constant: a runtime
@@ -1075,7 +1128,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv1d_mfma_kernel(const 
       return;
     }
   }
-  conv_consume<C, EPI, ACT, TM, TN>(a, P, lds, b, m0, t0, p0, wave / C::kWN, wave % C::kWN, lane, nchunks, lkc, xvec);
+  if constexpr (C::kKS > 1) {
+    const int ks = wave / (C::kWM * C::kWN), w2 = wave % (C::kWM * C::kWN);
+    conv_consume<C, EPI, ACT, TM, TN>(a, P, lds, b, m0, t0, p0, w2 / C::kWN, w2 % C::kWN, lane, nchunks, lkc, xvec, ks);
+  } else {
+    conv_consume<C, EPI, ACT, TM, TN>(a, P, lds, b, m0, t0, p0, wave / C::kWN, wave % C::kWN, lane, nchunks, lkc, xvec);
+  }
 }
 
 // -------------------------------------------------------------------- host side
@@ -1093,6 +1151,7 @@ int pick_lkc(const hsp_conv1d_args& a, int lds_limit) {
     const LdsPlan P = make_plan<C>(a.K, a.dil, a.prologue, lkc);
     if (P.total * (int)sizeof(float) > lds_limit) continue;
     if (P.kc < Prod<C>::RPI) continue;   // a weight DMA instruction must stay inside one tap
+    if (C::kKS > 1 && (((a.K * P.kc) >> 1) % (2 * C::kKS) != 0 || P.total < C::kWM * C::kWN * (32 * 36 + C::kTM * C::kTN * 16 * 64))) continue;  // even shares; room for the partial sums
     if (act && P.rpw > 2) continue;      // activation work per producer wave and chunk
     return lkc;
   }
@@ -1185,12 +1244,13 @@ using S64G = Cfg<1, 4, 2, 1, 4, 2>;    //  64 x 128  short sequences, gated rows
 using S32 = Cfg<1, 4, 1, 1, 4, 2>;     //  32 x 128
 using S64W = Cfg<2, 2, 1, 1, 4, 2, 128>;   //  64 x 64 with a 192-float window pitch: halos of 62 ... 125 columns
 using S64GW = Cfg<1, 4, 2, 1, 4, 2, 128>;  //  64 x 128 gated rows with a 256-float pitch (WN with dilation_rate > 1)
+using S64G2 = Cfg<1, 2, 2, 1, 4, 2, 64, 2>;  // 64 x 64 gated rows, the K range of a chunk split between two wave pairs (round 5)
 
 }  // namespace hspconv
 
 // One function per tile shape (hsp_conv1d_tile.hip, compiled once per shape): launches the instantiation
 // for (epi, act) or returns HSP_EINVAL when the shape does not carry that combination.
-#define HSP_TILE_LIST(X) X(M128) X(M64) X(M32) X(M64P) X(M32P) X(S64) X(S64G) X(S32) X(S64W) X(S64GW)
+#define HSP_TILE_LIST(X) X(M128) X(M64) X(M32) X(M64P) X(M32P) X(S64) X(S64G) X(S32) X(S64W) X(S64GW) X(S64G2)
 #define HSP_TILE_DECL(name) \
   int hsp_conv_tile_##name(const hsp_conv1d_args& a, int epi, bool act, hipStream_t s, int32_t* plan_out);
 HSP_TILE_LIST(HSP_TILE_DECL)

@@ -5,7 +5,7 @@
 #include "hsp_conv1d_mfma_kernel.h"
 
 #ifndef HSP_TILE
-#error "compile with -DHSP_TILE=<M128|M64|M32|M64P|M32P|S64|S64G|S32|S64W|S64GW>"
+#error "compile with -DHSP_TILE=<M128|M64|M32|M64P|M32P|S64|S64G|S32|S64W|S64GW|S64G2>"
 #endif
 
 namespace {
@@ -17,7 +17,7 @@ constexpr bool same = std::is_same<A, B>::value;
 
 template <int EPI, bool ACT>
 constexpr bool supported() {
-  if (same<T, S64G> || same<T, S64GW>) return EPI == HSP_EPI_GATE && !ACT;
+  if (same<T, S64G> || same<T, S64GW> || same<T, S64G2>) return EPI == HSP_EPI_GATE && !ACT;
   if (same<T, M64> || same<T, M32>) return ACT && (EPI == HSP_EPI_INIT || EPI == HSP_EPI_GEN);  // activation shapes
   if (ACT) return (same<T, M128> || same<T, S64> || same<T, S64W> || same<T, S32>) && (EPI == HSP_EPI_INIT || EPI == HSP_EPI_GEN);
   if (EPI == HSP_EPI_GATE) return same<T, M128>;

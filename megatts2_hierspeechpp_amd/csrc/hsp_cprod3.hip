@@ -88,6 +88,8 @@ __device__ __forceinline__ void cp_consume(const hsp_cprod3_args& a, float* cons
                                            const int wm, const int wn, const int lane, const int nchunks) {
   const int C = a.C, Np = a.Np;
   const int l32 = lane & 31, half = lane >> 5;
+  __builtin_assume(nchunks > 0);    // cp_check: C is a positive multiple of 64 (tools/check_isa.py: without this the compiler
+                                    // keeps a "no chunk" exit that runs the epilogue under the first reads still in flight)
   f32x16 k1[NB], k2[NB], k3[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n)

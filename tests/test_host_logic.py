@@ -469,6 +469,9 @@ def test_isa_lint_finds_a_fragment_used_before_its_wait(tmp_path):
                       + rd("v10", "v1") + ".LBB0_2:\n\tv_add_f32_e32 v3, v4, v5\n\ts_cmp_eq_u32 s8, s56\n\ts_cbranch_scc1 .LBB0_3\n"
                       + wait(0) + "\tv_mov_b32_e32 v20, v10\n\ts_branch .LBB0_1\n.LBB0_3:\n\tv_mov_b32_e32 v10, v7\n\ts_endpgm\n", 0),
     }
+    # ... and the same with the exit test's operands the other way round (what hipcc emits for hsp_cprod3.hip)
+    cases["loop_exit_swapped"] = (cases["loop_exit"][0].replace("s_cmp_eq_u32 s8, s56", "s_cmp_eq_u32 s56, s8")
+                                  .replace("s_cmp_lt_i32 s8, s56\n\ts_cbranch_scc0", "s_cmp_ge_u32 s8, s56\n\ts_cbranch_scc1"), 0)
     for name, (text, want) in cases.items():
         f = tmp_path / f"{name}.s"
         f.write_text(text)

@@ -148,7 +148,12 @@ def lint_kernel(path, kernel, ins, findings):
             m = re.fullmatch(r"s_cmp_(lt|le|gt|ge|eq|lg)_[iu]32", op)
             if m:
                 ab = [t.strip() for t in operands.split(",")]
-                last_cmp = (ab[0], ab[1], CMP[m.group(1)]) if len(ab) == 2 else None
+                last_cmp = None
+                if len(ab) == 2:
+                    rel = CMP[m.group(1)]
+                    if ab[0] > ab[1]:                           # one key per operand pair: `s_cmp_eq s28, s1` meets `s_cmp_ge s1, s28`
+                        ab, rel = [ab[1], ab[0]], rel.translate(str.maketrans("<>", "><"))
+                    last_cmp = (ab[0], ab[1], rel)
                 i += 1
                 continue
             if op.startswith("s_") and not op.startswith(("s_nop", "s_barrier", "s_sleep", "s_setprio", "s_sethalt")):
