@@ -1915,3 +1915,38 @@ def test_frequency_domain_form_falls_back_beyond_its_addressing(device, monkeypa
     yd = blk(x)
     assert torch.equal(y, yd)
     assert float((y481 - yd[:481]).abs().max()) <= 2e-5 * max(1.0, float(yd.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bins,C_,Np", [(3, 64, 4), (8, 64, 132), (5, 128, 256), (16, 64, 100), (2, 192, 36)])
+def test_cprod3_entry_point_vs_numpy(bins, C_, Np, device):
+    """hsp_cprod3_f32 called through the C ABI on arbitrary matrices (not a conv's): per bin Yr = k1 - k3, Yi = k1 + k2 with
+    k1 = A1 Xr, k2 = A2 (Xi - Xr), k3 = A3 (Xr + Xi) (include/hsp.h), against numpy in float64.  Bin counts that are and are
+    not multiples of 8 (the XCD-aware block order and the plain one), column counts on / off the 128-column tile, one to
+    three row tiles; and the argument checks."""
+    from megatts2_hierspeechpp_amd import _lib as L
+    rng = np.random.default_rng(bins * 1000 + C_ + Np)
+    xf = rng.standard_normal((bins, 2 * C_, Np)).astype(np.float32)
+    w = (rng.standard_normal((bins, 3, C_, C_)) / np.sqrt(C_)).astype(np.float32)      # [bin][matrix][ci][m]
+    xr, xi = xf[:, :C_].astype(np.float64), xf[:, C_:].astype(np.float64)
+    A = w.astype(np.float64).transpose(0, 1, 3, 2)                                      # [bin][matrix][m][ci]
+    k1, k2, k3 = A[:, 0] @ xr, A[:, 1] @ (xi - xr), A[:, 2] @ (xr + xi)
+    ref = np.concatenate([k1 - k3, k1 + k2], axis=1)
+    dxf, dw = torch.from_numpy(xf).to(device), torch.from_numpy(w).to(device)
+    yf = torch.full_like(dxf, float("nan"))
+    zeros = torch.zeros(64, device=device)
+    a = L.Cprod3Args()
+    a.xf, a.yf, a.w, a.zeros = L.fptr(dxf), L.fptr(yf), L.fptr(dw), L.fptr(zeros)
+    a.xf_bs = a.yf_bs = 2 * C_ * Np
+    a.bins, a.C, a.Np = bins, C_, Np
+    lib = L.lib()
+    assert lib.hsp_cprod3_supported(C.byref(a)) == 1
+    L.check(lib.hsp_cprod3_f32(C.byref(a), L.stream_ptr()), "hsp_cprod3_f32")
+    torch.cuda.synchronize()
+    _close(yf.cpu().numpy(), ref.astype(np.float32), f"cprod3 bins={bins} C={C_} Np={Np}")
+    for field, bad in (("C", C_ + 32), ("Np", Np + 2), ("bins", 0), ("debug", 1), ("xf_bs", 2 * C_ * Np - 4)):
+        keep = getattr(a, field)
+        setattr(a, field, bad)
+        assert lib.hsp_cprod3_supported(C.byref(a)) == 0 and lib.hsp_cprod3_f32(C.byref(a), L.stream_ptr()) == L.EINVAL, field
+        setattr(a, field, keep)
+    assert lib.hsp_cprod3_f32(None, L.stream_ptr()) == L.EINVAL
