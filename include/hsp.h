@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define HSP_VERSION 100 /* 0.1.0 */
+#define HSP_VERSION 101 /* 0.1.1: round 5 -- hsp_dftseg_args grew a field (prod3); hsp_cprod3_f32, hsp_cprod3_supported,
+                           * hsp_dftseg_weight_spectrum_f32, hsp_dftseg_supported are new */
 #define HSP_EINVAL (-1)
 
 int hsp_version(void);
@@ -454,8 +455,10 @@ int hsp_power_mel_log_f32(const float* spec, int64_t s_bs, int32_t s_ld, const f
  *                        of bin j of channel c (bin 0: DC in part 0, Nyquist in part 1); column n = (b * d + p) * nseg + s
  *                        is segment s of phase p (the samples xpad[p + d i]) of utterance b;
  *                        nseg = ceil(ceil(L / d) / (129 - k)), Np >= B d nseg (a multiple of 4)
- *   hsp_conv1d_mfma_f32  one launch: B = 64 (the bins), Cin = M = 2 C, K = 1, Lin = Np, w_bs = 4 C^2 -- per bin the real
- *                        block matrix [[Wr, Wi], [-Wi, Wr]] of conj(rfft(w, 128)) (bin 0: [[W_dc, 0], [0, W_nyquist]])
+ *   the channel product  ONE launch over the 64 bins, either of
+ *     hsp_cprod3_f32       (round 5, below; the forward transform then runs with prod3 = 1) three real C x C products per bin, or
+ *     hsp_conv1d_mfma_f32  B = 64 (the bins), Cin = M = 2 C, K = 1, Lin = Np, w_bs = 4 C^2 -- per bin the real block matrix
+ *                          [[Wr, Wi], [-Wi, Wr]] of conj(rfft(w, 128)) (bin 0: [[W_dc, 0], [0, W_nyquist]]); prod3 = 0
  *   hsp_dftseg_inv_f32   yf [64][2 C][Np] -> y [B][C][L] = ((corr + bias[c] + res) [+ y]) * post_scale
  * `dft` = the transform's constant table in device memory (HSP_DFTSEG_TABLE_FLOATS floats; hsp_dftseg_tables_f32 fills
  * the forward and the inverse one into host buffers): the 64 x 64 matrix of the radix-2 half-length real transform in
