@@ -24,7 +24,9 @@
 // immediate: no address arithmetic between the MFMAs.
 // Measured and not kept (same-box A/B of the 32 x 4 s step, profiles/r05_ab_cprod3_waveshape.json): consumer waves of
 // 64 rows x 32 columns instead of 32 x 64 -- two VALU instructions per six MFMAs instead of four, but eight fragment reads
-// instead of seven and every wave fetching all of the tile's A fragments: 58.96 against 58.72 ms per step.
+// instead of seven and every wave fetching all of the tile's A fragments: 58.96 against 58.72 ms per step; s_setprio 2 on
+// the consumer waves: 59.04 against 58.65 (the producers' DMA issue falls behind), on the producer waves: 58.70 / 58.75; the
+// epilogue through an LDS transpose with 16-B stores (a quarter of the store instructions): 58.99 against 58.59.
 #include "hsp_conv1d_mfma_kernel.h"
 
 namespace {
