@@ -8,4 +8,4 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmc_dftseg_b -- python3 $R/tools/dftseg_eager.py --reps 1 > $R/gpurun_out/pmc_dftseg_b.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmc_dftseg_c -- python3 $R/tools/dftseg_eager.py --reps 1 > $R/gpurun_out/pmc_dftseg_c.log 2>&1
 ls $R/gpurun_out/pmc_dftseg_a/* $R/gpurun_out/pmc_dftseg_b/* $R/gpurun_out/pmc_dftseg_c/* | head
-tail -2 $R/gpurun_out/pmc_dftseg_a.log $R/gpurun_out/pmc_dftseg_c.log
+tail -n 2 $R/gpurun_out/pmc_dftseg_a.log

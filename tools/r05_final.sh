@@ -10,6 +10,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_smoke.log 2>
 bash tools/profile_final.sh && cd $R &&
 bash tools/pmc_traffic.sh && cd $R &&
 bash tools/pmc_traffic_extra.sh && cd $R &&
+bash tools/pmc_dftseg.sh; cd $R
 python bench.py > gpurun_out/r05_bench_final.json 2> gpurun_out/r05_bench_final.err
 tail -c 300 gpurun_out/r05_bench_final.json
 timeout -k 10 900 python tools/fftconv_table.py > gpurun_out/r05_fftconv_dispatch_table.txt 2> gpurun_out/r05_fftconv_dispatch_table.err
