@@ -4,7 +4,9 @@ The recipe follows SURVEY.md §8(c)/(d): every tensor is drawn from a generator 
 ``(seed, crc32(key))`` so any side (golden-vector script, tests, bench, each rank of a
 multi-GPU run) can regenerate any tensor independently of iteration order.
 
-* weight-normed layers: ``weight_v ~ N(0,1)``, ``weight_g = 0.5``
+* weight-normed layers: ``weight_v ~ N(0,1)``, ``weight_g ~ U(0.3, 0.7)`` per element (round 6: a constant gain
+  would hide a gain applied along the wrong axis -- ConvTranspose1d carries one per INPUT channel, the wav2vec2
+  positional conv one per TAP; mean 0.5 keeps SURVEY §8(c)'s conditioning)
 * biases ``0.1·N``; SnakeBeta ``alpha, beta ~ 0.5·N``
 * plain conv / linear weights ``N(0,1)/sqrt(fan_in)`` (this also re-randomises the layers
   the reference zero-initialises -- ``post`` and ``adaLN_modulation`` -- without which
@@ -47,8 +49,8 @@ def synth_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
     r = _rng(seed, key)
     leaf = key.rsplit(".", 1)[-1]
     n = lambda: r.standard_normal(shape).astype(np.float32)
-    if leaf == "weight_g":
-        return np.full(shape, 0.5, np.float32)
+    if leaf == "weight_g":                             # a gain per channel / tap: U(0.3, 0.7), mean 0.5 (SURVEY §8c conditioning)
+        return r.uniform(0.3, 0.7, shape).astype(np.float32)
     if leaf == "weight_v":
         return n()
     if leaf == "bias":

@@ -807,7 +807,7 @@ def test_frequency_domain_conv_vs_torch(C_, k, d, L, B, device):
     with torch.no_grad():
         for p_ in lay.parameters():
             p_.copy_(torch.randn(p_.shape, generator=g))
-        lay.weight_g.fill_(0.5)
+        lay.weight_g.copy_(0.3 + 0.4 * torch.rand(lay.weight_g.shape, generator=g))
     lay.enable_fft()
     w = (lay.weight_g.data * lay.weight_v.data / lay.weight_v.data.flatten(1).norm(dim=1).view(-1, 1, 1)).double()
     bias = lay.bias.data.clone().double()
@@ -1198,7 +1198,7 @@ def test_block_token_gemm_second_output(device):
     with torch.no_grad():
         for p_ in lay.parameters():
             p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
-        lay.weight_g.fill_(0.5)
+        lay.weight_g.copy_(0.3 + 0.4 * torch.rand(lay.weight_g.shape, generator=g))
     finalize(lay, device)
     acts, x = torch.randn(B, H_, T, generator=g).to(device), torch.randn(B, H_, T, generator=g).to(device)
     mask = (torch.rand(B, 1, T, generator=g) > 0.2).float().to(device)
@@ -1298,7 +1298,7 @@ def test_second_output_gemm_matches_two_launches(device):
         with torch.no_grad():
             for p_ in lay.parameters():
                 p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
-            lay.weight_g.fill_(0.5)
+            lay.weight_g.copy_(0.3 + 0.4 * torch.rand(lay.weight_g.shape, generator=g))
         finalize(lay, device)
         acts = torch.randn(B, H_, T, generator=g).to(device)
         x = torch.randn(B, H_, T, generator=g).to(device)
@@ -1673,7 +1673,7 @@ def test_frequency_domain_conv_with_its_activation_fused(C_, k, d, L, B, device)
     with torch.no_grad():
         for p_ in m.conv.parameters():
             p_.copy_(torch.randn(p_.shape, generator=g))
-        m.conv.weight_g.fill_(0.5)
+        m.conv.weight_g.copy_(0.3 + 0.4 * torch.rand(m.conv.weight_g.shape, generator=g))
         m.act.act.alpha.copy_(0.3 * torch.randn(C_, generator=g))
         m.act.act.beta.copy_(0.3 * torch.randn(C_, generator=g))
     m.conv.enable_fft()
@@ -1723,7 +1723,7 @@ def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, k2, device):
         for c in (m.c1, m.c2):
             for p_ in c.parameters():
                 p_.copy_(torch.randn(p_.shape, generator=g))
-            c.weight_g.fill_(0.5)
+            c.weight_g.copy_(0.3 + 0.4 * torch.rand(c.weight_g.shape, generator=g))
         for a in (m.a1, m.a2):
             a.act.alpha.copy_(0.3 * torch.randn(C_, generator=g))
             a.act.beta.copy_(0.3 * torch.randn(C_, generator=g))
@@ -1759,7 +1759,7 @@ def _fft_layer(C_, k, d, g, device):
     with torch.no_grad():
         for p_ in lay.parameters():
             p_.copy_(torch.randn(p_.shape, generator=g))
-        lay.weight_g.fill_(0.5)
+        lay.weight_g.copy_(0.3 + 0.4 * torch.rand(lay.weight_g.shape, generator=g))
     lay.enable_fft()
     w = (lay.weight_g.data * lay.weight_v.data / lay.weight_v.data.flatten(1).norm(dim=1).view(-1, 1, 1)).double()
     bias = lay.bias.data.clone().double()
@@ -1899,7 +1899,7 @@ def test_frequency_domain_form_falls_back_beyond_its_addressing(device, monkeypa
         for n_, p_ in blk.named_parameters():
             p_.copy_(0.3 * torch.randn(p_.shape, generator=g))
         for c in list(blk.convs1) + list(blk.convs2):
-            c.weight_g.fill_(0.5)
+            c.weight_g.copy_(0.3 + 0.4 * torch.rand(c.weight_g.shape, generator=g))
     hip_layers.finalize(blk, device)
     x = torch.randn(482, 128, 16000, generator=g).to(device)
     assert not hss.fft_wins(blk.convs1[0], x) and hss.fft_wins(blk.convs1[0], x[:481])

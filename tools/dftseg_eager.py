@@ -31,7 +31,7 @@ class Pair(torch.nn.Module):
         self.a2 = Activation1d(activations.SnakeBeta(C_, alpha_logscale=True))
         for c in (self.c1, self.c2):
             c.weight_v.data.normal_()
-            c.weight_g.data.fill_(0.5)
+            c.weight_g.data.uniform_(0.3, 0.7)
             c.enable_fft()
 
 
