@@ -36,6 +36,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libhsp.so is built with -fvisibility=hidden: exactly the functions declared between this push and the pop at the end
+ * of the header are exported (`nm -D --defined-only libhsp.so` lists these names and nothing else; tests/test_host_logic.py). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HSP_VERSION 101 /* 0.1.1: round 5 -- hsp_dftseg_args grew a field (prod3); hsp_cprod3_f32, hsp_cprod3_supported,
                            * hsp_dftseg_weight_spectrum_f32, hsp_dftseg_supported are new */
@@ -568,6 +573,9 @@ int hsp_layernorm_modulate_f32(const float* x, float* y, int32_t B, int32_t C, i
                                const float* mask, const float* shift, const float* scale, int64_t mod_bs,
                                void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def build(verbose: bool = False) -> str:
+    """`make all` = libhsp.so AND the ISA lint of every hand-scheduled translation unit (tools/check_isa.py over the
+    device assembly; csrc/Makefile `build/isa/.checked`): a library whose fragment pipelines fail the lint does not build."""
     cmd = ["make", "-C", os.path.join(HERE, "csrc"), "-j4"]
     res = subprocess.run(cmd, capture_output=not verbose, text=True)
     if res.returncode != 0:
@@ -29,7 +31,7 @@ def source_id() -> str:
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")))
-    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(root, "include", "hsp.h")]
+    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(here, "csrc", "hsp.map"), os.path.join(root, "include", "hsp.h")]
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())

@@ -39,10 +39,13 @@ UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / ana
 # following conv (no HBM round trip) or as its own HBM-bound launch in front of a plain conv.
 # On MI355X the fp32 MFMA shares the SIMD's fp32 datapath with the VALU, so prologue arithmetic
 # is paid in MFMA time; layers with more input channels than this run the activation unfused.
-# With the wave-per-segment activation kernel (3.7-4.3 TB/s) and the plain low-channel convs at
-# two workgroups per CU the un-fused form wins at every width of the vocoder (DESIGN.md §5:
-# 104.4 / 102.5 / 101.3 ms per step for thresholds 64 / 32 / 0), so the default is 0; the fused
-# prologue stays available (and tested) behind this knob.
+# Measured again with every later kernel set, always the same order: round 4 (DESIGN.md §5.4
+# item 23, wave-per-segment activation kernel at 4.8 TB/s, frequency-domain k = 7 / 11 convs):
+# 80.5 / 84.1 / 78.3 ms per 32 x 4 s step for thresholds 32 / 64 / 0 (round 1, DESIGN.md §5
+# item 6: 102.5 / 104.4 / 101.3).  So the default is 0 -- the direct k = 3 convs read an
+# activation tensor written by its own launch, the frequency-domain convs fuse theirs into the
+# forward transform's staging (hsp_dftseg_args.act_*) -- and the fused conv prologue stays
+# available (and tested) behind this knob.
 FUSE_ACT_MAX_CHANNELS = int(os.environ.get("HSP_FUSE_ACT_MAX_C", "0"))
 
 

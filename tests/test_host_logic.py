@@ -152,6 +152,47 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.hsp_version() == 101 and lib.hsp_arch() == b"gfx950"
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """`nm -D --defined-only libhsp.so` lists the functions include/hsp.h declares and nothing else (-fvisibility=hidden,
+    the header's visibility push, csrc/hsp.map): no mangled helper, kernel handle or __hip_cuid_* leaks out of the boundary."""
+    import shutil
+    import subprocess
+    from megatts2_hierspeechpp_amd import _lib
+    if shutil.which("nm") is None:
+        pytest.skip("binutils nm not available")
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == sorted(_declared_symbols()), set(exported) ^ set(_declared_symbols())
+
+
+def test_isa_lint_passes_on_the_real_kernel_sources():
+    """The lint is part of `make all` (csrc/Makefile: build/isa/.checked) -- so a library built by build() has passed it;
+    here it runs again over the device assembly of the REAL translation units (not the synthetic kernels of the test
+    below) whenever hipcc is present, compiling the assembly first if a bare `make lib` left it out."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "megatts2_hierspeechpp_amd", "csrc")
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    res = subprocess.run(["make", "-C", csrc, "-j4", "check-isa"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-4000:]
+    files = sorted(glob.glob(os.path.join(csrc, "build", "isa", "*.s")))
+    assert len(files) >= 15, files
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    reads = 0
+    for f in files:
+        if not f.endswith(("hsp_cprod3.s", "hsp_dftseg.s", "hsp_conv1d_tile_M128.s")):
+            continue                                     # the three largest hand-scheduled units again, in-process (~15 s)
+        findings, n = check_isa.lint(f)
+        assert not findings, (f, findings[:3])
+        reads += n
+    assert reads > 200, reads
+
+
 def test_ctypes_structs_match_the_header(tmp_path):
     """sizeof / offsetof of the argument structs as gcc sees include/hsp.h == the ctypes mirrors."""
     from megatts2_hierspeechpp_amd import _lib
