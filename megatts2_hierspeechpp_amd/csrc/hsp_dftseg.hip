@@ -144,6 +144,19 @@ __device__ __forceinline__ int ds_div(int e, int ng, float inv_ng) {
   q -= r < 0 ? 1 : 0;
   return q;
 }
+// col -> (channel row, phase, segment) with float-reciprocal divisions (columns of an item: < 2^13)
+__device__ __forceinline__ DsCol ds_col_f(int col, int ncols, int d, int S, float inv_per, float inv_S) {
+  DsCol c;
+  c.ok = col < ncols;
+  const int cc = c.ok ? col : ncols - 1;
+  const int per = d * S;
+  c.ch = ds_div(cc, per, inv_per);
+  const int rem = cc - c.ch * per;
+  c.p = d == 1 ? 0 : ds_div(rem, S, inv_S);
+  c.s = rem - c.p * S;
+  return c;
+}
+
 __device__ __forceinline__ void ds_stage_load(const hsp_dftseg_args& a, const DsItem& I, const DsStage& s, int e0, int t,
                                               ds_f32x4 (&v)[16]) {
   const float* xb = a.x + (int64_t)I.b * a.x_bs + (int64_t)I.c0 * a.x_cs;
@@ -386,10 +399,11 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     // ---- the transform of item `it`
     const int S = Ic.S, ncols = Ic.ncg * d * S;
+    const float ipc = 1.0f / (float)(d * S), isc = 1.0f / (float)S;   // (round 6: column decode by float reciprocals)
     const float* buf = lds + shc;                               // sample 0 of row 0
     const int step = 4 * d;                                     // floats between the even (odd) taps of consecutive k-steps
     for (int cb = 32 * pairw; cb < ncols; cb += 64) {
-      const DsCol q = ds_col(cb + l32, ncols, d, S);
+      const DsCol q = ds_col_f(cb + l32, ncols, d, S, ipc, isc);
       const float* bp = buf + q.ch * pitch + q.p + d * (q.s * hop + 2 * half);
       ds_f32x16 ae, ao;                                         // E = F64 x[even], O = F64 x[odd]
 #pragma unroll
@@ -450,39 +464,122 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 // ---------------------------------------------------------------------------------------------------------- inverse
-// Epilogue of the conv this replaces, y = ((corr + bias + res) [+ y]) * post_scale, out of the LDS stretch: slice
-// `sl` of `nsl` of the item's rows, by `nthr` threads.  W floats per thread and strip; eight strips per thread at a
-// time, the residual / running-sum loads of all of them in flight together.
-template <int W>
+// (round 6)  The index arithmetic of this kernel used to cost 14.7 vector instructions per MFMA (profiles/r05_dftseg_pmc.txt)
+// -- and the fp32 MFMA shares its issue with the VALU, so every one of them was paid in matrix time.  What was there and
+// where it went:
+//   * sixteen 64-bit addresses per thread and block for the spectrum loads  ->  four wave-uniform 64-bit bases (the
+//     planes of this wave's first bin, Re / Im, X[k] / X[64 - k]: scalar registers) + a 32-bit byte offset per load = the
+//     column's offset + a per-thread constant (eight v_add per block; the host bounds the spectrum of a launch to 4 GB);
+//   * the column decode col -> (channel row, phase, segment), two integer divisions, done twice per block (fetch, scatter)
+//     ->  float-reciprocal divisions (ds_div), once: the fetch hands its decode to the scatter two steps later with the
+//     register set;
+//   * a bounds test per scattered sample  ->  none: a row's stretch holds d S hop floats, every index the scatter can form
+//     is inside it, and the epilogue reads [0, tl) only (the samples past the tensor's end land in the row's own slack);
+//     the `i < hop` test is compile-time true except for the last four accumulator registers of the odd wave halves;
+//   * an epilogue that divided every strip index by the strips per row and multiplied 64-bit strides per element  ->
+//     a wave owns UNITS of 64 U consecutive vectors of one row: row base addresses on the scalar unit, one 32-bit byte
+//     offset per vector.
+// Same arithmetic in the same order as before: results are bit-identical to round 5's kernel.
+
+// Epilogue of the conv this replaces, y = ((corr + bias + res) [+ y]) * post_scale, out of the LDS stretch of an item.
+// A UNIT = 64 U consecutive W-float vectors of one row; wave w of nw takes units w, w + nw, ...: the row's base addresses
+// (y, res) are wave-uniform 64-bit values, a lane adds one 32-bit byte offset per vector.
+template <int W, int U>
 __device__ __forceinline__ void ds_inv_epilogue(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const float* buf,
-                                                int sl, int nsl, int t, int nthr, int tb, int tl) {
+                                                int w, int nw, int lane, int tb, int tl) {
   typedef float vec_t __attribute__((ext_vector_type(W)));
-  const int nel = tl / W;                                       // elements per row
-  const int R = (nel + nthr - 1) / nthr;                        // strips per row
-  const int T = I.ncg * R;
-  const int q_lo = (int)((int64_t)sl * T / nsl), q_hi = (int)((int64_t)(sl + 1) * T / nsl);
-  for (int q0 = q_lo; q0 < q_hi; q0 += 8) {
-    vec_t r4[8], o4[8];
-    float bz[8];
+  const int nel = tl / W;                                       // vectors per row
+  const int R = (nel + 64 * U - 1) / (64 * U);                  // units per row
+  const bool has_res = a.res != nullptr, acc = a.accumulate != 0;
+  const float ps = a.post_scale;
+  int ch = 0, rr = w;
+  while (rr >= R) rr -= R, ++ch;                                // (uniform)
+  while (ch < I.ncg) {
+    const int c = I.c0 + ch;
+    const float bz = a.bias ? a.bias[c] : 0.0f;
+    char* const yb = reinterpret_cast<char*>(a.y + (int64_t)I.b * a.y_bs + (int64_t)c * a.y_cs + tb);
+    const char* const rb = has_res ? reinterpret_cast<const char*>(a.res + (int64_t)I.b * a.res_bs + (int64_t)c * a.res_cs + tb) : nullptr;
+    const float* const row = buf + ch * G.pitch;
+    const int j0 = rr * (64 * U) + lane;
+    vec_t r4[U], o4[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int q = min(q0 + u, q_hi - 1), ch = q / R, c = I.c0 + ch;
-      const int j = min((q - ch * R) * nthr + t, nel - 1);
-      const int64_t yo = (int64_t)I.b * a.y_bs + (int64_t)c * a.y_cs + tb + W * j;
-      bz[u] = a.bias ? a.bias[c] : 0.0f;
-      r4[u] = a.res ? *reinterpret_cast<const vec_t*>(a.res + (int64_t)I.b * a.res_bs + (int64_t)c * a.res_cs + tb + W * j) : vec_t(0.0f);
-      o4[u] = a.accumulate ? *reinterpret_cast<const vec_t*>(a.y + yo) : vec_t(0.0f);
+    for (int u = 0; u < U; ++u) {
+      const unsigned off = (unsigned)(min(j0 + 64 * u, nel - 1) * (W * 4));
+      r4[u] = has_res ? *reinterpret_cast<const vec_t*>(rb + off) : vec_t(0.0f);
+      o4[u] = acc ? *reinterpret_cast<const vec_t*>(yb + off) : vec_t(0.0f);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int q = q0 + u, ch = min(q, q_hi - 1) / R;
-      const int j = (q - ch * R) * nthr + t;
-      if (q < q_hi && j < nel) {
-        const vec_t v = *reinterpret_cast<const vec_t*>(buf + ch * G.pitch + W * j);
-        *reinterpret_cast<vec_t*>(a.y + (int64_t)I.b * a.y_bs + (int64_t)(I.c0 + ch) * a.y_cs + tb + W * j) =
-            (v + bz[u] + r4[u] + o4[u]) * a.post_scale;
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + 64 * u;
+      if (j < nel) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(row + W * j);
+        *reinterpret_cast<vec_t*>(yb + (unsigned)(j * (W * 4))) = (v + bz + r4[u] + o4[u]) * ps;
       }
     }
+    rr += nw;
+    while (rr >= R) rr -= R, ++ch;
+  }
+}
+
+// The spectrum side of a thread: it recombines the bins kf(u) = 8 w + 4 half + u, u < 4, of one column, i.e. it loads
+// X[kf] and X[64 - kf] (bin 0's thread: (DC | Nyquist) and X[32]), Re and Im.  Byte offset of a load = column offset +
+// c1[u] (c2[u]) from the uniform base b1 (b2), + `imb` for the Im part.
+struct DsInvSrc {
+  const char *b1, *b1i, *b2, *b2i;                              // wave-uniform
+  unsigned c1[4], c2[4];
+};
+__device__ __forceinline__ DsInvSrc ds_inv_src(const float* xf, int64_t xf_bs, int C, int Np, int w, int half) {
+  DsInvSrc s;
+  const unsigned rowb = 4u * (unsigned)xf_bs, imb = 4u * (unsigned)(C * Np);
+  const int kb = 8 * w;                                         // first bin of this wave
+  const int B2 = w == 0 ? 32 : 57 - kb;                         // 64 - kf = B2 + (m2 - 4 half - u), m2 - 4 half - u >= 0
+  const int m2 = w == 0 ? 32 : 7;
+  s.b1 = reinterpret_cast<const char*>(xf) + (size_t)kb * rowb;
+  s.b1i = s.b1 + imb;
+  s.b2 = reinterpret_cast<const char*>(xf) + (size_t)B2 * rowb;
+  s.b2i = s.b2 + imb;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    s.c1[u] = (unsigned)(4 * half + u) * rowb;
+    s.c2[u] = (unsigned)(m2 - 4 * half - u) * rowb;
+  }
+  if (w == 0 && half == 0) s.c2[0] = 0;                         // bin 0's thread: X[32] where the others read X[64 - kf]
+  return s;
+}
+__device__ __forceinline__ void ds_inv_fetch(const DsInvSrc& s, unsigned colb, float (&v)[16]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned o1 = colb + s.c1[u], o2 = colb + s.c2[u];
+    v[4 * u + 0] = *reinterpret_cast<const float*>(s.b1 + o1);
+    v[4 * u + 1] = *reinterpret_cast<const float*>(s.b1i + o1);
+    v[4 * u + 2] = *reinterpret_cast<const float*>(s.b2 + o2);
+    v[4 * u + 3] = *reinterpret_cast<const float*>(s.b2i + o2);
+  }
+}
+// E^ = X[k] + conj(X[64 - k]), O^ = (X[k] - conj(X[64 - k])) W^-k into the operand buffer [E^ | O^][64 slots][32 columns]
+// (the factor 1/2 is in the table); dst = the buffer + this lane's column
+__device__ __forceinline__ void ds_inv_stash(float* dst, int kf0, const float (&v)[16], const float (&twc)[4], const float (&tws)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kf = kf0 + u;
+    const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
+    const float dr = xr - yr, di = xi + yi;                     // X[k] - conj(X[64 - k])
+    const bool z = u == 0 && kf == 0;                           // (DC, Nyquist, Re X[32], Im X[32]): E^0 E^32 O^0 O^32 real
+    dst[kf * 32] = z ? xr + xi : xr + yr;                       // Re E^[k]
+    dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;              // Im E^[k]             (slot 32: E^[32] = 2 Re X[32])
+    dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];       // Re O^[k]
+    dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];    // Im O^[k]  (slot 32: O^[32] = -2 Im X[32])
+  }
+}
+// Scatter of a block's time samples into the LDS image of the output rows: accumulator register r of wave (eo, wh) is
+// sample i = 2 (32 wh + DS_ACC_ROW(r, half)) + eo of the column's segment; the first `hop` samples of a segment are
+// valid.  rp = the address of this lane's sample of register 0; no test against the tensor's end (see above).
+__device__ __forceinline__ void ds_inv_scatter(float* rp, int d, int i0, int hop, int wh, const ds_f32x16& acc, const ds_f32x16& acc2) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int cr = (r & 3) + 8 * (r >> 2);
+    // 2 (32 wh + cr + 4 half) + eo <= 63 < hop for every wh = 0 wave (hop >= 65: k <= 64); wh = 1 and r < 12: <= 95
+    if (wh == 0 || (r < 12 && hop >= 96) || i0 + 2 * cr < hop) rp[2 * d * cr] = acc[r] + acc2[r];
   }
 }
 
@@ -509,33 +606,27 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
     }
   }
   float* const bbuf = lds + G.bufsz;                            // [nbuf][E^ | O^][64 slots][32 columns]
+  const DsInvSrc src = ds_inv_src(a.xf, a.xf_bs, a.C, a.Np, wave, half);
+  const int kf0 = 8 * wave + 4 * half;
   // the epilogue runs in the scalar form unless every row it touches is 16-B addressable (workgroup-uniform)
   const bool vec0 = ((a.L | (int)a.y_bs | (int)a.y_cs | (int)a.res_bs | (int)a.res_cs) & 3) == 0 &&
                     ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0;
   // B operand of a column block: [E^ | O^][64 slots][32 columns], the same for all four waves, so it is staged through
   // LDS once.  A thread fetches X[k] and X[64 - k] (bin 0's thread: DC | Nyquist and X[32]) of four bins of one column
-  // -- every load instruction two 128-B runs -- and stores E^ = X[k] + conj(X[64 - k]), O^ = (X[k] - conj(X[64 - k]))
-  // W^-k (the factor 1/2 is in the table).  The fetches run TWO column blocks ahead of the MFMAs, across item
-  // boundaries (the first block of the next row is in flight under this row's epilogue): a block is 32 MFMAs per wave,
-  // 1 us, less than one HBM round trip.
+  // -- every load instruction two 128-B runs -- and stores E^, O^ (ds_inv_stash).  The fetches run TWO column blocks
+  // ahead of the MFMAs, across item boundaries (the first block of the next row is in flight under this row's epilogue):
+  // a block is 32 MFMAs per wave, 1 us, less than one HBM round trip.
   const int nmine = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   auto item_of = [&](int it) __attribute__((always_inline)) { return ds_item(blockIdx.x + it * gridDim.x, a, G); };
   int it_f = 0, blk_f = 0;                                      // the position the next fetch reads
   DsItem If = item_of(0);
   int ncols_f = If.ncg * d * If.S;
+  float ipf = 1.0f / (float)(d * If.S), isf = 1.0f / (float)If.S;
   bool more_f = true;
-  auto fetch_next = [&](float (&v)[16]) __attribute__((always_inline)) {
-    const DsCol q = ds_col(32 * blk_f + l32, ncols_f, d, If.S);
-    const float* src = a.xf + (int64_t)(If.c0 + q.ch) * a.Np + (If.b * d + q.p) * a.nseg + If.s0 + q.s;
-    const int64_t im = (int64_t)a.C * a.Np;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kf = 8 * wave + 4 * half + u, k2 = kf == 0 ? 32 : 64 - kf;
-      v[4 * u + 0] = src[(int64_t)kf * a.xf_bs];
-      v[4 * u + 1] = src[(int64_t)kf * a.xf_bs + im];
-      v[4 * u + 2] = src[(int64_t)k2 * a.xf_bs];
-      v[4 * u + 3] = src[(int64_t)k2 * a.xf_bs + im];
-    }
+  // fetch the next block of the fetch stream into v; q = its column decode (handed to the scatter two steps later)
+  auto fetch_next = [&](float (&v)[16], DsCol& q) __attribute__((always_inline)) {
+    q = ds_col_f(32 * blk_f + l32, ncols_f, d, If.S, ipf, isf);
+    ds_inv_fetch(src, 4u * (unsigned)((If.c0 + q.ch) * a.Np + (If.b * d + q.p) * a.nseg + If.s0 + q.s), v);
     // advance (behind the last block of the last item the position stays: two harmless repeats)
     if (32 * (blk_f + 1) < ncols_f) {
       ++blk_f;
@@ -544,22 +635,10 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
       blk_f = 0;
       If = item_of(it_f);
       ncols_f = If.ncg * d * If.S;
+      ipf = 1.0f / (float)(d * If.S);
+      isf = 1.0f / (float)If.S;
     } else {
       more_f = false;
-    }
-  };
-  auto stash = [&](int buf, const float (&v)[16]) __attribute__((always_inline)) {
-    float* dst = bbuf + buf * (128 * 32) + l32;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kf = 8 * wave + 4 * half + u;
-      const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
-      const float dr = xr - yr, di = xi + yi;                   // X[k] - conj(X[64 - k])
-      const bool z = u == 0 && kf == 0;                         // (DC, Nyquist, Re X[32], Im X[32]): E^0 E^32 O^0 O^32 real
-      dst[kf * 32] = z ? xr + xi : xr + yr;                     // Re E^[k]
-      dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;            // Im E^[k]             (slot 32: E^[32] = 2 Re X[32])
-      dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];       // Re O^[k]
-      dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];    // Im O^[k]  (slot 32: O^[32] = -2 Im X[32])
     }
   };
   // the position the MFMAs are at
@@ -567,19 +646,20 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
   DsItem I = item_of(0);
   int ncols = I.ncg * d * I.S;
   bool done = false;
+  const int i0 = 2 * (32 * wh + 4 * half) + eo;                 // sample (inside its segment) of accumulator register 0
   // One step = one column block: stage its operand (fetched two steps ago), refill the same registers with the block
   // two steps ahead, multiply, scatter; behind the last block of an item, its epilogue.  Called alternately with the
   // two register sets, so no set is ever copied (a copy would wait for the loads it copies).
-  auto step = [&](float (&v)[16]) __attribute__((always_inline)) {
-    const int S = I.S, nblk = (ncols + 31) >> 5;
-    const int tb = d * I.s0 * hop;                              // output index of row[0]
-    const int tl = min(a.L - tb, d * S * hop);                  // outputs of this chunk
+  auto step = [&](float (&v)[16], DsCol& qv) __attribute__((always_inline)) {
+    const int nblk = (ncols + 31) >> 5;
     // (the barrier behind the first stash of an item also says: everyone has left the previous item's epilogue)
-    stash(buf, v);
+    float* const ob = bbuf + buf * (128 * 32);
+    ds_inv_stash(ob + l32, kf0, v, twc, tws);
+    const DsCol q = qv;                                         // this block's decode, before the refill overwrites it
     ds_barrier();
-    fetch_next(v);                                              // in flight under this block's and the next one's MFMAs
+    fetch_next(v, qv);                                          // in flight under this block's and the next one's MFMAs
     {
-      const float* bp = bbuf + buf * (128 * 32) + eo * (64 * 32) + half * 32 + l32;
+      const float* bp = ob + eo * (64 * 32) + half * 32 + l32;
       ds_f32x16 acc, acc2;                                      // two chains: even / odd k-steps
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
@@ -588,16 +668,7 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks], bp[ks * 64], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks + 1], bp[ks * 64 + 64], acc2, 0, 0, 0);
       }
-      const DsCol q = ds_col(32 * blk_c + l32, ncols, d, S);
-      if (q.ok) {
-        float* row = lds + q.ch * pitch;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = 2 * (32 * wh + DS_ACC_ROW(r, half)) + eo;   // time inside the segment: the first hop are valid
-          const int j = q.p + d * (q.s * hop + i);              // index inside the chunk's stretch
-          if (i < hop && j < tl) row[j] = acc[r] + acc2[r];
-        }
-      }
+      if (q.ok) ds_inv_scatter(lds + q.ch * pitch + q.p + d * (q.s * hop + i0), d, i0, hop, wh, acc, acc2);
     }
     const bool last = blk_c + 1 == nblk;
     if (nbuf == 1 || last) ds_barrier();                        // the buffer is free again / the item is scattered
@@ -606,8 +677,10 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
       ++blk_c;
       return;
     }
-    if (vec0 && ((tb | tl) & 3) == 0) ds_inv_epilogue<4>(a, G, I, lds, 0, 1, tid, DS_MEM, tb, tl);
-    else ds_inv_epilogue<1>(a, G, I, lds, 0, 1, tid, DS_MEM, tb, tl);
+    const int tb = d * I.s0 * hop;                              // output index of row[0]
+    const int tl = min(a.L - tb, d * I.S * hop);                // outputs of this chunk
+    if (vec0 && ((tb | tl) & 3) == 0) ds_inv_epilogue<4, 4>(a, G, I, lds, wave, 4, lane, tb, tl);
+    else ds_inv_epilogue<1, 4>(a, G, I, lds, wave, 4, lane, tb, tl);
     if (++it_c < nmine) {
       blk_c = 0;
       I = item_of(it_c);
@@ -617,12 +690,13 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
     }
   };
   float v1[16], v2[16];
-  fetch_next(v1);
-  fetch_next(v2);
+  DsCol q1, q2;
+  fetch_next(v1, q1);
+  fetch_next(v2, q2);
   while (true) {
-    step(v1);
+    step(v1, q1);
     if (done) break;
-    step(v2);
+    step(v2, q2);
     if (done) break;
   }
 }
@@ -695,18 +769,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   DsItem If = item_of(0);
   int ncols_f = If.ncg * d1 * G.S1;
   bool more_f = true;
-  auto fetch_next = [&](float (&v)[16]) __attribute__((always_inline)) {
-    const DsCol q = ds_col(32 * (2 * st_f + grp) + l32, ncols_f, d1, G.S1);
-    const float* src = ai.xf + (int64_t)(If.c0 + q.ch) * ai.Np + (If.b * d1 + q.p) * ai.nseg + q.s;
-    const int64_t im = (int64_t)ai.C * ai.Np;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kf = 8 * w4 + 4 * half + u, k2 = kf == 0 ? 32 : 64 - kf;
-      v[4 * u + 0] = src[(int64_t)kf * ai.xf_bs];
-      v[4 * u + 1] = src[(int64_t)kf * ai.xf_bs + im];
-      v[4 * u + 2] = src[(int64_t)k2 * ai.xf_bs];
-      v[4 * u + 3] = src[(int64_t)k2 * ai.xf_bs + im];
-    }
+  const float ip1 = 1.0f / (float)(d1 * G.S1), is1 = 1.0f / (float)G.S1;
+  const DsInvSrc src = ds_inv_src(ai.xf, ai.xf_bs, ai.C, ai.Np, w4, half);
+  const int kf0 = 8 * w4 + 4 * half;
+  const int i0 = 2 * (32 * wh1 + 4 * half) + eo;                // sample (inside its segment) of accumulator register 0
+  // (round 6: addresses, column decode and scatter as in dftseg_inv_kernel -- four uniform bases + 32-bit offsets, float-
+  // reciprocal decode handed from the fetch to the scatter, no per-sample bounds test)
+  auto fetch_next = [&](float (&v)[16], DsCol& q) __attribute__((always_inline)) {
+    q = ds_col_f(32 * (2 * st_f + grp) + l32, ncols_f, d1, G.S1, ip1, is1);
+    ds_inv_fetch(src, 4u * (unsigned)((If.c0 + q.ch) * ai.Np + (If.b * d1 + q.p) * ai.nseg + q.s), v);
     if (64 * (st_f + 1) < ncols_f) {
       ++st_f;
     } else if (more_f && it_f + 1 < nmine) {
@@ -718,34 +789,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       more_f = false;
     }
   };
-  auto stash = [&](const float (&v)[16]) __attribute__((always_inline)) {
-    float* dst = bbuf + l32;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kf = 8 * w4 + 4 * half + u;
-      const float xr = v[4 * u], xi = v[4 * u + 1], yr = v[4 * u + 2], yi = v[4 * u + 3];
-      const float dr = xr - yr, di = xi + yi;
-      const bool z = u == 0 && kf == 0;
-      dst[kf * 32] = z ? xr + xi : xr + yr;
-      dst[(32 + kf) * 32] = z ? 2.0f * yr : xi - yi;
-      dst[(64 + kf) * 32] = z ? xr - xi : dr * twc[u] - di * tws[u];
-      dst[(96 + kf) * 32] = z ? -2.0f * yi : dr * tws[u] + di * twc[u];
-    }
-  };
   const DsGeom Gf = {G.cg, G.S2, G.pitchB, G.ngrp, 1, 0};        // what da_segment reads of the forward geometry: pitch
   float v1[16], v2[16];
-  fetch_next(v1);
-  fetch_next(v2);
+  DsCol q1, q2;
+  fetch_next(v1, q1);
+  fetch_next(v2, q2);
   __syncthreads();                                              // tables in LDS
   bool odd = false;                                             // which register set the next step stages
   for (int it = 0; it < nmine; ++it) {
     const DsItem I = item_of(it);
     const int ncols1 = I.ncg * d1 * G.S1, nst = (ncols1 + 63) >> 6;
     // ---------------- phase 1
-    auto step1 = [&](float (&v)[16], int st) __attribute__((always_inline)) {
-      stash(v);
+    auto step1 = [&](float (&v)[16], DsCol& qv) __attribute__((always_inline)) {
+      ds_inv_stash(bbuf + l32, kf0, v, twc, tws);
+      const DsCol q = qv;
       ds_barrier();
-      fetch_next(v);
+      fetch_next(v, qv);
       const float* bp = bbuf + eo * (64 * 32) + half * 32 + l32;
       ds_f32x16 acc, acc2;
 #pragma unroll
@@ -755,22 +814,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[ks], bp[ks * 64], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[ks + 1], bp[ks * 64 + 64], acc2, 0, 0, 0);
       }
-      const DsCol q = ds_col(32 * (2 * st + grp) + l32, ncols1, d1, G.S1);
-      if (q.ok) {
-        float* row = sA + q.ch * G.pitchA;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = 2 * (32 * wh1 + DS_ACC_ROW(r, half)) + eo;
-          const int j = q.p + d1 * (q.s * hop1 + i);
-          // (c1's bias joins in phase 2: a load in this branch would wait for the fetches just issued -- vmcnt(0))
-          if (i < hop1 && j < ai.L) row[j] = acc[r] + acc2[r];
-        }
-      }
+      // (c1's bias joins in phase 2: a load in this branch would wait for the fetches just issued -- vmcnt(0).  A block
+      // behind the item's last one has no valid column.  pitchA >= d1 S1 hop1: every index the scatter forms is inside
+      // its row, and phases 2 / 3 read [0, L) only.)
+      if (q.ok) ds_inv_scatter(sA + q.ch * G.pitchA + q.p + d1 * (q.s * hop1 + i0), d1, i0, hop1, wh1, acc, acc2);
       ds_barrier();                                             // the operand buffer is free / A is complete
     };
     for (int st = 0; st < nst; ++st) {
-      if (odd) step1(v2, st);
-      else step1(v1, st);
+      if (odd) step1(v2, q2);
+      else step1(v1, q1);
       odd = !odd;
     }
     // ---------------- phase 2: A -> act -> B
@@ -800,8 +852,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int step = 4 * d2;
       const unsigned rowb = 4u * (unsigned)af.xf_bs, imb = 4u * (unsigned)(af.C * af.Np);
       const int lanek = 16 * wh3 + 4 * half;
+      const float ip2 = 1.0f / (float)(d2 * G.S2), is2 = 1.0f / (float)G.S2;
       for (int cb = 32 * pw; cb < ncols2; cb += 128) {
-        const DsCol q = ds_col(cb + l32, ncols2, d2, G.S2);
+        const DsCol q = ds_col_f(cb + l32, ncols2, d2, G.S2, ip2, is2);
         const float* bp = buf + q.ch * G.pitchB + q.p + d2 * (q.s * hop2 + 2 * half);
         ds_f32x16 ae, ao;
 #pragma unroll

@@ -70,8 +70,15 @@ class ResidualCouplingBlock_Transformer(nn.Module):
             lin.__dict__["_stacked_elsewhere"] = True
         self.adaln_all = StackedLinearCT(lins)
         self._mod_rows = lins[0].cout * n_layers   # rows per coupling layer
+        # (round 6)  The Flips cost no launch: reverse runs `Flip, coupling` for i = n_flows - 1 ... 0, so the tensor
+        # reaches coupling i after n_flows - i flips; the layers that see an odd number of them work on the reversed
+        # channel axis through their packed weights (set_flipped).  n_flows odd leaves one real Flip at the end.
+        if modules.FOLD_FLIP:
+            for i in range(n_flows):
+                self.flows[2 * i].set_flipped((n_flows - i) % 2 == 1)
 
-    def forward(self, x, x_mask, g=None, reverse=False):
+    def forward(self, x, x_mask, g=None, reverse=False, owned=False):
+        """``owned``: the caller hands x over (a temporary of its own): the first coupling layer may update it in place."""
         if not reverse:
             raise NotImplementedError("training direction is out of scope")
         c = self.cond_block[0](g.reshape(g.shape[0], -1), act=L.ACT_SILU)
@@ -80,11 +87,17 @@ class ResidualCouplingBlock_Transformer(nn.Module):
         c_silu = self.cond_block[2](c, act=L.ACT_SILU)   # [B, hidden, 1]
         mods = self.adaln_all(c_silu)                    # [B, n_flows * n_layers * 6 * hidden, 1]
         R = self._mod_rows
+        flipped = False                                   # is the stored channel axis the reverse of the true one?
         for i in reversed(range(self.n_flows)):
-            x = self.flows[2 * i + 1](x, x_mask, reverse=True)                                  # Flip -> fresh tensor
-            x = self.flows[2 * i](x, x_mask, g=None, mods=mods[:, i * R:(i + 1) * R], reverse=True,
-                                  inplace=True)                                                 # coupling, in place
-        return x
+            layer = self.flows[2 * i]
+            if layer.flipped != (not flipped):
+                x = self.flows[2 * i + 1](x, x_mask, reverse=True)                              # Flip -> fresh tensor
+                owned = True
+            else:
+                flipped = not flipped                                                           # Flip, not launched
+            x = layer(x, x_mask, g=None, mods=mods[:, i * R:(i + 1) * R], reverse=True, inplace=owned)   # coupling
+            owned = True
+        return Fh.flip_channels(x) if flipped else x
 
 
 class PosteriorSFEncoder(nn.Module):
@@ -262,6 +275,14 @@ def fft_act(x) -> bool:
 # chain touches the shared accumulator; events serialise those three launches in block order,
 # so the sum is formed in the reference's order ((b0 + b1) + b2) / 3.
 AMP_STREAMS = int(os.environ.get("HSP_AMP_STREAMS", "1"))
+# (round 6; SURVEY.md §7 "stage ordering for cache")  HSP_GEN_GROUPS = G > 1: the stages of the
+# Generator with at most HSP_GEN_GROUP_MAX_C channels (default 128: L = 16 000 ... 64 000, 262-MB tensors at 32 x 4 s, just
+# past the 256-MB Infinity Cache) run as G SEQUENTIAL utterance groups -- each group walks ups -> AMP stage -> ... ->
+# conv_post before the next one starts, on the same three AMP streams -- so that a group's intermediates (65 MB at G = 4)
+# can stay cache-resident between the launch that writes them and the one that reads them.  Same launches per utterance,
+# bit-identical results (utterances are independent); measured in DESIGN.md §5.6.
+GEN_GROUPS = int(os.environ.get("HSP_GEN_GROUPS", "1"))
+GEN_GROUP_MAX_C = int(os.environ.get("HSP_GEN_GROUP_MAX_C", "128"))
 FRONT_SPLITS = int(os.environ.get("HSP_FRONT_SPLITS", "4"))
 # measurement mode (bench.py's per-launch pass, tools/pmc_traffic.sh): the SAME launches as the product step -- the front
 # part still cut into FRONT_SPLITS batch groups, the AMP chains unchanged -- but issued one after the other on the
@@ -387,13 +408,36 @@ class Generator(nn.Module):
     @_entry
     def forward(self, x, pitch, g=None):
         x = self.conv_pre(x, cbias=self.cond(g), res=self.downs(pitch))
-        for i in range(self.num_upsamples):
+        first_grouped = self.num_upsamples
+        if GEN_GROUPS > 1 and x.shape[0] >= 2 * GEN_GROUPS:
+            # the first stage whose channel count is at most GEN_GROUP_MAX_C: from there on the batch walks the rest of
+            # the Generator as sequential utterance groups (SURVEY.md §7 "stage ordering for cache")
+            chans = [self.ups[i].cout for i in range(self.num_upsamples)]
+            first_grouped = next((i for i, c in enumerate(chans) if c <= GEN_GROUP_MAX_C), self.num_upsamples)
+        for i in range(first_grouped):
             x = self.ups[i](x)
             if i == 0:
                 x = self.proj(pitch, res=x, out=x)
             x = _amp_stage(self.resblocks, i * self.num_kernels, self.num_kernels, x)
-        x = self.activation_post(x)
-        return self.conv_post(x, act=L.ACT_TANH)
+        if first_grouped == self.num_upsamples:
+            x = self.activation_post(x)
+            return self.conv_post(x, act=L.ACT_TANH)
+        B = x.shape[0]
+        total_up = 1
+        for i in range(first_grouped, self.num_upsamples):
+            total_up *= self.ups[i].up
+        out = torch.empty(B, 1, x.shape[2] * total_up, dtype=torch.float32, device=x.device)
+        bounds = [(B * j) // GEN_GROUPS for j in range(GEN_GROUPS + 1)]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            xg = x[lo:hi]
+            for i in range(first_grouped, self.num_upsamples):
+                xg = self.ups[i](xg)
+                if i == 0:
+                    xg = self.proj(pitch[lo:hi], res=xg, out=xg)
+                xg = _amp_stage(self.resblocks, i * self.num_kernels, self.num_kernels, xg)
+            xg = self.activation_post(xg)
+            self.conv_post(xg, act=L.ACT_TANH, out=out[lo:hi])
+        return out
 
 
 class SynthesizerTrn(nn.Module):
@@ -453,7 +497,7 @@ class SynthesizerTrn(nn.Module):
         n = min(FRONT_SPLITS, B)
         if n <= 1:
             z = self._prior(w2v, f0, y_mask, g, noise, noise_scale)
-            return self.flow(self.flow_l(z, y_mask, g=g, reverse=True), y_mask, g=g, reverse=True)
+            return self.flow(self.flow_l(z, y_mask, g=g, reverse=True, owned=True), y_mask, g=g, reverse=True, owned=True)
         if noise is None:
             noise = torch.randn(B, self.inter_channels, w2v.shape[2], dtype=torch.float32, device=w2v.device)
         main = torch.cuda.current_stream(w2v.device)
@@ -469,8 +513,8 @@ class SynthesizerTrn(nn.Module):
                 if i > 0 and st is not main:
                     st.wait_event(fork)
                 zi = self._prior(w2v[lo:hi], f0[lo:hi], y_mask[lo:hi], g[lo:hi], noise[lo:hi], noise_scale)
-                zi = self.flow_l(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True)
-                zi = self.flow(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True)
+                zi = self.flow_l(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True, owned=True)
+                zi = self.flow(zi, y_mask[lo:hi], g=g[lo:hi], reverse=True, owned=True)
                 z[lo:hi].copy_(zi)
                 if i > 0 and st is not main:
                     ev = torch.cuda.Event()

@@ -385,6 +385,18 @@ class Conv1d(_ConvBase):
         assert self.k == 1 and self.rows == L.ROWS_PLAIN
         self.__dict__["_rowmajor"] = True
 
+    def pack_flipped(self, inputs: bool = False, outputs: bool = False):
+        """Pack this layer for a tensor whose channel axis is stored REVERSED: ``inputs`` -- the input channels arrive in
+        reverse order (the packed weight's input columns are reversed), ``outputs`` -- the output channels are to be
+        written in reverse order (rows and bias reversed).  The parameters and their state-dict keys stay as the
+        reference stores them; only the packed copy changes.  This is how modules.Flip (modules.py:270-277) between two
+        coupling layers costs no launch: the layer after a Flip reads and writes the un-flipped tensor through a packed
+        weight that has the permutation in it (modules.ResidualCouplingLayer_Transformer_simple.flipped)."""
+        assert self.rows == L.ROWS_PLAIN and not self.__dict__.get("_pre_norm") and not self.__dict__.get("_rowmajor")
+        self.__dict__["_flip_in"], self.__dict__["_flip_out"] = bool(inputs), bool(outputs)
+        self.__dict__["_hsp_stale"] = True
+        _bump_epoch()
+
     def hsp_requests(self):
         if self.__dict__.get("_stacked_elsewhere"):   # rows live in a StackedLinearCT: parameters only
             return []
@@ -436,6 +448,10 @@ class Conv1d(_ConvBase):
         self._wf = None                                   # derived from _w on first use (ensure_wf)
         if materialize:
             w = self._folded()
+            if self.__dict__.get("_flip_in"):
+                w = w.flip(1).contiguous()
+            if self.__dict__.get("_flip_out"):
+                w = w.flip(0).contiguous()
             if self._wt is not None:
                 assert not fused
                 self._wt.copy_(w.reshape(self.cout, self.cin))
@@ -451,7 +467,7 @@ class Conv1d(_ConvBase):
                 w = wg.float().reshape(w.shape).contiguous()
             _gather(w, conv_pack_map(self.cout, self.cin, self.k, self.row_map), self._w)
             if self._b is not None and not fused:
-                self._b.copy_(self._bias_src())
+                self._b.copy_(self._bias_src().flip(0) if self.__dict__.get("_flip_out") else self._bias_src())
 
     # The frequency-domain form in pieces (forward_fft strings them together; an AMP pair fuses the inverse of its first
     # conv with the forward transform of its second: forward_fft_pair)
@@ -632,7 +648,7 @@ class Conv1d(_ConvBase):
     # ----------------------------------------------------------------------------
     def forward(self, x, *, act1d=None, lrelu: Optional[float] = None, silu_in=False, act=L.ACT_NONE, cbias=None,
                 mask=None, mask_mode=L.MASK_NONE, cscale=None, scale=1.0, res=None, out=None, accumulate=False,
-                post_scale=1.0, force_direct=False, row_range=None, split_out=None):
+                post_scale=1.0, force_direct=False, row_range=None, split_out=None, mask_mode2=L.MASK_NONE):
         """``row_range=(r0, r1)`` computes only output channels [r0, r1) (PLAIN rows, r0 % 4 == 0):
         the WN res/skip layer is one parameter set feeding two differently-fused launches.
         ``split_out=(split_row, out2, accumulate2)``: ONE launch for both halves of such a layer
@@ -697,7 +713,7 @@ class Conv1d(_ConvBase):
                       + rows_full * Cin * self.k)
         if split_out is not None:
             a.Cout = self.cout                      # rows [split_row, cout) go to the second output
-            a.split_row, a.accumulate2, a.mask_mode2 = split_row, int(bool(acc2)), L.MASK_NONE
+            a.split_row, a.accumulate2, a.mask_mode2 = split_row, int(bool(acc2)), mask_mode2   # (the second output shares `mask`)
             a.y2, a.y2_bs, a.y2_cs = L.fptr(out2), out2.stride(0), out2.stride(1)
             flops = 2 * B * self.cout * Cin * Lout
             nbytes += 4 * B * (self.cout - split_row) * Lout * (1 + bool(acc2))

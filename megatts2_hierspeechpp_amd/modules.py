@@ -17,6 +17,9 @@ from . import hip_layers
 from .hip_layers import Conv1d, HipLayer, Linear
 
 LRELU_SLOPE = 0.1  # modules.py:17
+# (round 6, VERDICT r05 item 1b: shorter dependent launch chains in the 50 Hz part)
+FOLD_MASK = os.environ.get("HSP_FOLD_MASK", "1") == "1"   # WN: the final mask multiply inside the skip launches
+FOLD_FLIP = os.environ.get("HSP_FOLD_FLIP", "1") == "1"   # coupling blocks: Flip inside the next layer's packed pre / post
 
 def _fuse(x) -> bool:
     """Route a WN layer / DiT FFN through the entry points SURVEY.md 8(b) names for them (hsp_wn_layer_f32,
@@ -85,6 +88,10 @@ class WN(nn.Module):
         out = None
         acts = torch.empty(x.shape[0], H, x.shape[2], dtype=torch.float32, device=x.device)
         fuse = _fuse(x)
+        # The final `output * x_mask` (modules.py:176) is applied where each skip contribution is produced: a 0/1 mask
+        # times every term of the sum IS the mask times the sum, bit for bit (mask(s_1 + ... + s_n): the same additions on
+        # the kept columns, exact zeros on the others) -- one launch per WN less (round 6; HSP_FOLD_MASK=0: the old form)
+        skip_mask = L.MASK_PRE if (FOLD_MASK and x_mask is not None) else L.MASK_NONE
         for i in range(self.n_layers):
             cb = gc[:, 2 * H * i: 2 * H * (i + 1)] if gc is not None else None
             last = i == self.n_layers - 1
@@ -93,28 +100,31 @@ class WN(nn.Module):
                 # (hsp_conv1d_args.split_row; None = the library has no such kernel for this shape)
                 self.in_layers[i](x, cbias=cb, out=acts)
                 both = self.res_skip_layers[i](acts, res=x, mask=x_mask, mask_mode=L.MASK_POST,
-                                               split_out=(H, out, out is not None))
+                                               split_out=(H, out, out is not None), mask_mode2=skip_mask)
                 if both is not None:
                     x, out = both
                     continue
                 x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
-                out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
+                out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None,
+                                              mask=x_mask, mask_mode=skip_mask)
                 x = x_new
                 continue
             with (hip_layers.deferred() if fuse else contextlib.nullcontext()) as args:
                 self.in_layers[i](x, cbias=cb, out=acts)
                 if not last:
                     x_new = self.res_skip_layers[i](acts, row_range=(0, H), res=x, mask=x_mask, mask_mode=L.MASK_POST)
-                    out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None)
+                    out = self.res_skip_layers[i](acts, row_range=(H, 2 * H), out=out, accumulate=out is not None,
+                                                  mask=x_mask, mask_mode=skip_mask)
                 else:
-                    # last layer: output = output + rs (modules.py:175-176); the final * x_mask follows below
-                    out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None)
+                    # last layer: output = output + rs (modules.py:175-176)
+                    out = self.res_skip_layers[i](acts, out=out, accumulate=out is not None, mask=x_mask,
+                                                  mask_mode=skip_mask)
             if fuse:
                 hip_layers.launch_group("hsp_wn_layer_f32", L.lib().hsp_wn_layer_f32,
                                         [args[0], args[1] if not last else None, args[-1]])
             if not last:
                 x = x_new
-        return Fh.mask_mul(out, x_mask)
+        return out if skip_mask != L.MASK_NONE else Fh.mask_mul(out, x_mask)
 
 
 class Flip(nn.Module):
@@ -213,13 +223,26 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
         self.enc_block = nn.ModuleList([DiTConVBlock(hidden_channels, 2, mlp_ratio=4.0, kernel=5, p_dropout=p_dropout)
                                         for _ in range(n_layers)])
         self.post = Conv1d(hidden_channels, self.half_channels, 1)
+        self.flipped = False
+
+    def set_flipped(self, flipped: bool):
+        """``flipped``: this layer is called on a tensor whose channel axis is stored REVERSED -- the Flip in front of it
+        (modules.py:270-277; hierspeechpp_speechsynthesizer.py:80-86 runs `Flip, coupling` pairs in reverse) was not
+        launched.  flip(x)[:, :half] is x[:, half:] reversed and flip(x)[:, half:] is x[:, :half] reversed, so the layer
+        reads x[:, half:] through a `pre` packed with reversed input columns and updates x[:, :half] through a `post`
+        packed with reversed rows: flip(result) is what the reference's layer returns on flip(x).  Same products, the
+        input-channel sum of `pre` runs in the opposite order (not bit-identical, equally accurate)."""
+        self.flipped = bool(flipped)
+        self.pre.pack_flipped(inputs=self.flipped)
+        self.post.pack_flipped(outputs=self.flipped)
 
     def forward(self, x, x_mask, g=None, reverse=False, inplace=False, c_silu=None, mods=None):
         """``mods`` [B, n_layers * 6 * hidden, 1]: the adaLN outputs of this layer's blocks, stacked."""
         if not reverse:
             raise NotImplementedError("training direction (logdet) is out of scope")
         half = self.half_channels
-        h = self.pre(x[:, :half], mask=x_mask, mask_mode=L.MASK_PRE)
+        rd, wr = (slice(half, None), slice(0, half)) if self.flipped else (slice(0, half), slice(half, None))
+        h = self.pre(x[:, rd], mask=x_mask, mask_mode=L.MASK_PRE)
         R = 6 * self.hidden_channels
         for j, blk in enumerate(self.enc_block):
             # `pre` and every block's last launch multiply by the mask before the residual add: h stays masked
@@ -227,5 +250,5 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
                     premasked=True)
         out = x if inplace else x.clone()
         # x1 <- (x1 - post(h) * mask) * mask          (modules.py:473,486)
-        self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, half:], out=out[:, half:])
+        self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, wr], out=out[:, wr])
         return out

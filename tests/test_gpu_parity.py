@@ -410,6 +410,26 @@ def test_full_size_batch_properties(full_model, device):
             assert err <= 2e-5, f"utterance {b}: batch vs alone differ by {err:.2e}"
 
 
+def test_generator_as_sequential_utterance_groups(full_model, device, monkeypatch):
+    """HSP_GEN_GROUPS (SURVEY.md §7 "stage ordering for cache", hierspeechpp_speechsynthesizer.py:440-446 in the reference):
+    the C <= 128 stages of the Generator walked by 2 / 4 sequential utterance groups give what the whole batch gives
+    (utterances are independent; a group may take another tile shape or conv form than the whole batch, so the bar is the
+    batch-vs-alone one, not bit equality)."""
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from megatts2_hierspeechpp_amd import synth
+    inp = synth.synth_inputs(8, 100, seed=606)
+    d = {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
+    with torch.no_grad():
+        o1, e1 = full_model.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+        for groups in (2, 4):
+            monkeypatch.setattr(hss, "GEN_GROUPS", groups)
+            o2, e2 = full_model.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+            assert o2.shape == o1.shape and torch.equal(e1, e2)
+            err = float((o1 - o2).abs().max())
+            assert err <= 2e-5, f"{groups} groups: {err:.2e}"
+        monkeypatch.setattr(hss, "GEN_GROUPS", 1)
+
+
 def test_full_size_one_utterance_vs_oracle(full_model, device):
     """One 4-s utterance of the full-size batch against the oracle (about 10 s of CPU)."""
     from megatts2_hierspeechpp_amd import synth
