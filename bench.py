@@ -586,6 +586,11 @@ def main(argv=None):
             extra["tts_2x16"] = bench_extra.tts_2x16(torch_device(), steps=3, models=models)
             _progress("extra_configs: full TTS, batch 1")
             extra["tts_b1"] = bench_extra.tts_b1(torch_device(), steps=3, models=models)
+            _progress("extra_configs: TTS from the prompt waveform with the denoiser (SURVEY 8f N4)")
+            extra["tts_prompt_denoise"] = bench_extra.tts_prompt_denoise(torch_device(), steps=3, models=models)
+            del models
+            _progress("extra_configs: voice conversion 1 x 4 s (SURVEY 8f N2)")
+            extra["vc_b1_4s"] = bench_extra.vc_b1_4s(torch_device(), steps=10)
             result["extra_configs"] = extra
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(result) + "\n").encode())

@@ -321,6 +321,14 @@ def _fold(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     return w
 
 
+def _spectrum(Cc: int, Np: int, device) -> torch.Tensor:
+    """[64 bins][2 C][Np] spectrum buffer of a frequency-domain conv.  (Round 6 measured a padded plane stride -- 64 or 1088
+    floats between the bins, so that the 128 scattered 128-B runs of a column do not share an address pattern modulo the HBM
+    channel interleave: no effect on any transform kernel, 147.3 / 147.7 / 147.9 us per inverse launch,
+    profiles/r06_plane_pad.txt; the knob is gone.)"""
+    return torch.empty(64, 2 * Cc, Np, dtype=torch.float32, device=device)
+
+
 class _ConvBase(HipLayer):
     def __init__(self, weight_shape, rows0: int, bias: bool, weight_norm: bool):
         super().__init__()
@@ -503,7 +511,7 @@ class Conv1d(_ConvBase):
         B, Cc, Lx = x.shape
         assert Cc == self.cin and x.stride(2) == 1 and self.__dict__.get("_fft")
         da = self._fft_args(B, Lx)
-        xf = torch.empty(64, 2 * Cc, da.Np, dtype=torch.float32, device=x.device)
+        xf = _spectrum(Cc, da.Np, x.device)
         da.x, da.x_bs, da.x_cs = L.fptr(x), x.stride(0), x.stride(1)
         da.xf, da.xf_bs, da.dft = L.fptr(xf), xf.stride(0), L.fptr(_dft_tables(x.device)[0])
         if act1d is not None:
@@ -525,7 +533,7 @@ class Conv1d(_ConvBase):
         (hsp_cprod3_f32) or the [2C x 2C] block matrix [[Wr, Wi], [-Wi, Wr]] on the conv kernel."""
         Cc, Np = self.cin, xf.shape[2]
         wf = self.ensure_wf()
-        yf = torch.empty_like(xf)
+        yf = _spectrum(Cc, Np, xf.device)
         if self._wf_form == "three":
             pa = L.Cprod3Args()
             pa.xf, pa.yf, pa.w, pa.zeros = L.fptr(xf), L.fptr(yf), L.fptr(wf), L.fptr(_zeros(xf.device))
@@ -624,7 +632,7 @@ class Conv1d(_ConvBase):
         yf = self._fft_product(xf)
         ia = self._fft_inverse_args(yf, B, Lx)
         fa = second._fft_args(B, Lx)
-        xf2 = torch.empty(64, 2 * Cc, fa.Np, dtype=torch.float32, device=x.device)
+        xf2 = _spectrum(Cc, fa.Np, x.device)
         fa.xf, fa.xf_bs, fa.dft = L.fptr(xf2), xf2.stride(0), L.fptr(_dft_tables(x.device)[0])
         self._fft_set_act(fa, x, act_second)
         hook = LAUNCH_HOOK

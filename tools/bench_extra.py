@@ -21,6 +21,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_EXTRA = "r06_traffic_extra.json"   # tools/pmc_traffic_extra.sh + tools/pmc_summarize_extra.py
 
 VOC_CFG = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,
                p_dropout=0.1, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
@@ -78,11 +79,11 @@ def conv_entry_profile(fn):
 
 def _pmc_traffic(workload, kind, launches):
     """HBM bytes per launch of `kind` from the committed PMC profile of this workload's dominant stage
-    (profiles/r05_traffic_extra.json, tools/pmc_traffic_extra.sh), or (None, reason)."""
+    (profiles/<TRAFFIC_EXTRA>, tools/pmc_traffic_extra.sh), or (None, reason)."""
     import json
-    path = os.path.join(ROOT, "profiles", "r05_traffic_extra.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_EXTRA)
     if workload is None or not os.path.exists(path):
-        return None, "no profiles/r05_traffic_extra.json"
+        return None, f"no profiles/{TRAFFIC_EXTRA}"
     from megatts2_hierspeechpp_amd.build import source_id
     tj = json.load(open(path))
     if tj.get("kernel_source_sha16") != source_id():
@@ -234,6 +235,161 @@ def tts_b16(dev, steps=3, warmup=1, batch=16, phones=40, use_graph=True, models=
             "stage_ms_note": "one extra step with EAGER launches behind the PLM graph so that events can sit between the stages "
                              "(the timed flow replays that half from one hipGraph, ~6 ms faster than the eager sum)",
             "roofline": roof}
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(f) N2 / N4 on the bench line
+def _speechlike(n, seed):
+    """a deterministic speech-like waveform (harmonics of a gliding pitch + noise, |x| < 1): the prompt / source audio"""
+    r = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    f0 = 120.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t)
+    ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+    x = sum(np.sin(k * ph) / k for k in range(1, 6)) * (0.5 + 0.5 * np.sin(2 * np.pi * 2.1 * t) ** 2)
+    x = 0.25 * x + 0.02 * r.standard_normal(n)
+    return (x / max(1.0, np.abs(x).max() / 0.95)).astype(np.float32)[None]
+
+
+def vc_b1_4s(dev, steps=10, seconds=4.0, prompt_seconds=3.0):
+    """The reference's second way into the vocoder (inference_vc.py:70-145): ONE source utterance of `seconds` of 16 kHz audio
+    -> reflect pad -> wav2vec2 (MMS-300M topology) hidden state 7 -> F0 conversion against the prompt's track ->
+    prompt mels -> voice_conversion_noise_control -> int16.  The YAAPT F0 tracks are inputs (CPU numpy code of a third-party
+    package in the reference; absent here), drawn like synth_inputs' f0.  hipGraph replay of the whole tensor core; stage
+    split from an eager pass with events; `roofline` = the dominant kernel of the wav2vec2 producer behind the conv entry points."""
+    from megatts2_hierspeechpp_amd import functional as Fh, inference_vc as IV, synth
+    from megatts2_hierspeechpp_amd.Mels_preprocess import MelSpectrogramFixed
+    from megatts2_hierspeechpp_amd.inference_plm import peak_int16
+    models = IV.VcModels(VOC_CFG)
+    models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0)) for k, v in models.state_dict().items()})
+    models.finalize(dev)
+    mel_fn = MelSpectrogramFixed(sample_rate=16000, n_fft=1280, win_length=1280, hop_length=320, f_min=0, f_max=8000,
+                                 n_mels=80, window_fn=torch.hann_window).finalize(dev)
+    n_src = int(seconds * 16000) - 640                       # pad_source always adds: 4 s after padding
+    src = IV.pad_source(torch.from_numpy(_speechlike(n_src, 11)).to(dev))
+    trg = torch.from_numpy(_speechlike(int(prompt_seconds * 16000), 12)).to(dev)
+    T = src.shape[-1] // 320
+    r = np.random.default_rng(13)
+    mk_f0 = lambda n: torch.from_numpy(np.where(r.random((1, n)) < 0.3, 0, r.uniform(90, 300, (1, n))).astype(np.float32)).to(dev)
+    f0s, f0t = mk_f0(4 * T), mk_f0(trg.shape[-1] // 80)
+    noise = torch.from_numpy(r.standard_normal((1, 192, T)).astype(np.float32)).to(dev)
+
+    def stages(mark):
+        mark()
+        x_w2v = models.w2v(Fh.reflect_pad(src, 40))
+        mark()
+        lf0 = Fh.f0_convert(f0s, f0t)
+        both = torch.cat([trg, trg], 0)
+        trg_mel = mel_fn(both)
+        mark()
+        xl = torch.full((1,), T, dtype=torch.int64, device=dev)
+        tl = torch.full((2,), trg_mel.shape[2], dtype=torch.int64, device=dev)
+        audio = models.voc.voice_conversion_noise_control(x_w2v, xl, trg_mel, tl, lf0.reshape(1, -1)[:, :4 * T],
+                                                          noise_scale=0.333, denoise_ratio=0.0, noise=noise)
+        mark()
+        wav = peak_int16(audio.reshape(1, -1), torch.full((1,), audio.shape[-1], dtype=torch.int64, device=dev))
+        mark()
+        return wav
+
+    wav = stages(lambda: None)
+    torch.cuda.synchronize()
+    assert wav.shape == (1, 320 * T) and wav.dtype == torch.int16
+    # the harness entry point itself gives the same samples (it builds its length tensors on the host)
+    ref = IV.vc(models, mel_fn, src, f0s, trg, f0t, noise_scale_vc=0.333, denoise_ratio=0.0, noise=noise)
+    assert torch.equal(ref, wav.reshape(-1))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        stages(lambda: None)
+    g.replay()
+    torch.cuda.synchronize()
+    ms = event_median_ms(g.replay, steps)
+    ev = []
+    stages(lambda: ev.append(torch.cuda.Event(enable_timing=True)) or ev[-1].record())
+    torch.cuda.synchronize()
+    names = ["wav2vec2_hidden7(N2)", "f0_convert+prompt_mels(N1,N2)", "vocoder(A1-A14)", "int16_post(A19)"]
+    stage_ms = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
+    gw = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gw):
+        models.w2v(Fh.reflect_pad(src, 40))
+    gw.replay()
+    torch.cuda.synchronize()
+    w2v_ms = event_median_ms(gw.replay, steps)
+    roof = dominant_roofline(conv_entry_profile(lambda: models.w2v(Fh.reflect_pad(src, 40))), "vc_w2v")
+    if roof:
+        roof["scope"] = ("the wav2vec2 producer only (7 strided feature convs at 512 channels + positional conv + 7 transformer "
+                         "layers of 1024 / 4096): the dominant kernel among the launches behind the conv entry points")
+    return {"metric": "latency of the inference_vc.py tensor core, 1 utterance x 4 s (SURVEY 8(f) N2)",
+            "value": 320 * T / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms, "rtf": ms * 1e-3 / (T / 50.0),
+            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
+            "config": {"workload": f"vc: 1 x {T / 50:g} s source (reflect pad 40 -> wav2vec2 hidden state 7, {T} frames), "
+                                   f"{prompt_seconds:g}-s prompt, F0 tracks given",
+                       "launch_mode": "hipGraph replay of the whole tensor core, median of HIP-event pairs"},
+            "stage_ms": stage_ms, "stage_ms_note": "one eager pass with events between the stages (host submission included)",
+            "w2v_producer_graph_ms": w2v_ms, "roofline": roof}
+
+
+def tts_prompt_denoise(dev, steps=3, models=None, prompt_seconds=3.0, phones=40):
+    """inference_plm.py's default call (denoise_ratio = 0.8, :308-309): prompt WAVEFORM -> MP-SENet denoiser (denoiser/infer.py:4-33)
+    -> two prompt mels -> text -> w2v / f0 -> vocoder with the mixed style vector -> int16; ONE utterance of 40 phones x 10
+    frames = 4 s, as the reference runs it.  Eager launches (the flow holds the reference's host read-backs); the denoiser's
+    share is timed alone (eager, event pairs) and the `roofline` is its dominant kernel behind the conv entry points."""
+    import types
+    from megatts2_hierspeechpp_amd import inference_plm as IP, synth
+    from megatts2_hierspeechpp_amd.Mels_preprocess import MelSpectrogramFixed
+    from megatts2_hierspeechpp_amd.denoiser.generator import MPNet
+    from megatts2_hierspeechpp_amd.denoiser.infer import denoise
+    hd = types.SimpleNamespace(dense_channel=64, compress_factor=0.3, num_tsconformers=4, beta=2.0, sampling_rate=16000,
+                               n_fft=400, hop_size=100, win_size=400)   # denoiser/config.json of the reference
+    if models is None:
+        models = IP.TtsModels(VOC_CFG, TTV_CFG)
+        models.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0)) for k, v in models.state_dict().items()})
+        models.finalize(dev)
+    den = MPNet(hd)
+    den.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 7)) for k, v in den.state_dict().items()})
+    den.finalize(dev)
+    mel_fn = MelSpectrogramFixed(sample_rate=16000, n_fft=1280, win_length=1280, hop_length=320, f_min=0, f_max=8000,
+                                 n_mels=80, window_fn=torch.hann_window).finalize(dev)
+    r = np.random.default_rng(3)
+    N = phones
+    ids = torch.from_numpy(r.integers(12, 113, (1, N))).to(dev)
+    tone = torch.from_numpy(r.integers(0, 11, (1, N))).to(dev)
+    lang = torch.where(ids < 74, 1, 2).to(dev)
+    prompt = torch.from_numpy(_speechlike(int(prompt_seconds * 16000), 21)).to(dev)
+    dur = torch.full((1, N), 10.0, device=dev)
+    T2 = N * 10 // 2
+    noise = torch.from_numpy(r.standard_normal((1, 192, T2)).astype(np.float32)).to(dev)
+    run = lambda ratio: IP.tts_from_prompt(models, mel_fn, ids, tone, lang, prompt, dur=dur, noise=noise, denoise_ratio=ratio,
+                                           denoiser=den if ratio else None, hps_denoiser=hd)
+    wav = run(0.8)
+    torch.cuda.synchronize()
+    assert wav.shape == (320 * T2,) and wav.dtype == torch.int16
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    ms = timed(lambda: run(0.8))
+    ms_plain = timed(lambda: run(0.0))
+    padded = torch.zeros((prompt.shape[-1] // 1600 + 1) * 1600, device=dev)
+    padded[:prompt.shape[-1]].copy_(prompt[0])
+    denoise(padded, den, hd)
+    torch.cuda.synchronize()
+    # eager: denoise() reads the prompt's energy back for its norm factor (denoiser/infer.py:5: a host value in the reference too)
+    den_ms = event_median_ms(lambda: denoise(padded, den, hd), 10)
+    roof = dominant_roofline(conv_entry_profile(lambda: denoise(padded, den, hd)), "denoiser")
+    if roof:
+        roof["scope"] = ("the prompt denoiser only (MP-SENet: dense encoder, 4 two-stage conformers over 161 time x 201 frequency "
+                         "positions per second, two decoders): the dominant kernel among the launches behind the conv entry points")
+    return {"metric": "latency of inference_plm.py text->wav from the prompt waveform with denoise_ratio = 0.8, 1 utterance x 4 s "
+                      "(SURVEY 8(f) N4 + N1)",
+            "value": 320 * T2 / (ms * 1e-3), "unit": "samples/s", "ms_per_step": ms, "rtf": ms * 1e-3 / (T2 / 50.0),
+            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "steps": steps,
+            "config": {"workload": f"tts_from_prompt: {prompt_seconds:g}-s prompt waveform -> denoiser -> prompt mels -> {N} phones x 10 "
+                                   f"frames -> {T2 / 50:g} s", "launch_mode": "eager (the reference's host read-backs stay)"},
+            "ms_per_step_without_denoiser": ms_plain, "denoiser_ms": den_ms,
+            "denoiser_share": den_ms / ms, "roofline": roof}
 
 
 # ----------------------------------------------------------------------------- configs[3]

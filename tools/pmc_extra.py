@@ -2,7 +2,9 @@
 """One warm-up + one measured EAGER pass of the dominant stage of an extra config, for `rocprofv3 --pmc` (graph-replayed
 kernels are invisible to the profiler; tools/pmc_traffic_extra.sh wraps this):
     tts   BASELINE.json configs[2]: the PLM greedy loop on the x_frame of the batch-16 TTS workload (200 steps, eager)
-    sr48  BASELINE.json configs[3]: the SpeechSR48 stage on the vocoder's 32 x 4 s output"""
+    sr48  BASELINE.json configs[3]: the SpeechSR48 stage on the vocoder's 32 x 4 s output
+    vc_w2v    extra_configs.vc_b1_4s: the wav2vec2 producer on 4 s of padded source audio
+    denoiser  extra_configs.tts_prompt_denoise: the MP-SENet denoiser on the padded 3-s prompt"""
 import os
 import sys
 
@@ -38,6 +40,31 @@ elif which == "sr48":
     for _ in range(2):
         sr(o)
     torch.cuda.synchronize()
+elif which == "vc_w2v":
+    from megatts2_hierspeechpp_amd import functional as Fh, inference_vc as IV
+    from megatts2_hierspeechpp_amd.extract_w2v import Wav2vec2
+    from megatts2_hierspeechpp_amd.hip_layers import finalize
+    w2v = Wav2vec2(layer=7)
+    w2v.load_state_dict({k: torch.from_numpy(synth.synth_tensor("w2v." + k, tuple(v.shape), 0)) for k, v in w2v.state_dict().items()})
+    finalize(w2v, dev)
+    src = IV.pad_source(torch.from_numpy(BE._speechlike(64000 - 640, 11)).to(dev))
+    for _ in range(2):
+        w2v(Fh.reflect_pad(src, 40))
+    torch.cuda.synchronize()
+elif which == "denoiser":
+    import types
+    from megatts2_hierspeechpp_amd.denoiser.generator import MPNet
+    from megatts2_hierspeechpp_amd.denoiser.infer import denoise
+    hd = types.SimpleNamespace(dense_channel=64, compress_factor=0.3, num_tsconformers=4, beta=2.0, sampling_rate=16000,
+                               n_fft=400, hop_size=100, win_size=400)
+    den = MPNet(hd)
+    den.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 7)) for k, v in den.state_dict().items()})
+    den.finalize(dev)
+    padded = torch.zeros(49600, device=dev)
+    padded[:48000].copy_(torch.from_numpy(BE._speechlike(48000, 21)).to(dev)[0])
+    for _ in range(2):
+        denoise(padded, den, hd)
+    torch.cuda.synchronize()
 else:
-    raise SystemExit("tts | sr48")
+    raise SystemExit("tts | sr48 | vc_w2v | denoiser")
 print("done", which)

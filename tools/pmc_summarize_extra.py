@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold tools/pmc_traffic_extra.sh's passes into profiles/r05_traffic_extra.json (keyed by the kernel-source hash):
+"""Fold tools/pmc_traffic_extra.sh's passes into profiles/r06_traffic_extra.json (keyed by the kernel-source hash):
 per workload and kernel class the launches and the FETCH_SIZE / WRITE_SIZE KB of ONE pass (the script runs two).
 tools/bench_extra.py quotes `roofline.traffic` of extra_configs from it when the hash matches."""
 import csv
@@ -18,6 +18,7 @@ CLASSES = ["conv1d_mfma_kernel", "cprod3_kernel", "wspec_kernel", "dftseg_fwd_ke
            "mha_tok_kernel", "mha_mfma_kernel", "mha_kernel", "layernorm", "conv1d_cout1_kernel", "conv1d_direct_kernel",
            "linear_interp", "plm_embed", "argmax"]
 PASSES = 2
+WORKLOADS = ("tts", "sr48", "vc_w2v", "denoiser")
 
 
 def cls(name):
@@ -31,7 +32,7 @@ res = {"kernel_source_sha16": source_id(), "passes_in_run": PASSES,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_extra.py; KB per ONE pass of the stage. "
                "FETCH_SIZE under-reports 16-B-per-lane streams by the factor calibrated in r05_traffic.json (conv / LDS-DMA token "
                "GEMM); the register-path GEMM reads 4 B per lane, where round 1 measured 0.90 of the true bytes."}
-for w in ("tts", "sr48"):
+for w in WORKLOADS:
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(f"{src}/trafficx_{w}_{counter}/**/*counter_collection.csv", recursive=True)
@@ -47,5 +48,5 @@ for w in ("tts", "sr48"):
         k["launches"] //= PASSES
     res[w] = out
 json.dump(res, open(dst, "w"), indent=1)
-for w in ("tts", "sr48"):
+for w in WORKLOADS:
     print(w, {k: (v["launches"], round(v["FETCH_SIZE_KB"] / 1e6, 3), round(v["WRITE_SIZE_KB"] / 1e6, 3)) for k, v in res[w].items()})
