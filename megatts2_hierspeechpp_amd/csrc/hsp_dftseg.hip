@@ -484,13 +484,12 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // Epilogue of the conv this replaces, y = ((corr + bias + res) [+ y]) * post_scale, out of the LDS stretch of an item.
 // A UNIT = 64 U consecutive W-float vectors of one row; wave w of nw takes units w, w + nw, ...: the row's base addresses
 // (y, res) are wave-uniform 64-bit values, a lane adds one 32-bit byte offset per vector.
-template <int W, int U>
-__device__ __forceinline__ void ds_inv_epilogue(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const float* buf,
-                                                int w, int nw, int lane, int tb, int tl) {
+template <int W, int U, bool RES, bool ACC>
+__device__ __forceinline__ void ds_inv_epilogue_t(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const float* buf,
+                                                  int w, int nw, int lane, int tb, int tl) {
   typedef float vec_t __attribute__((ext_vector_type(W)));
   const int nel = tl / W;                                       // vectors per row
   const int R = (nel + 64 * U - 1) / (64 * U);                  // units per row
-  const bool has_res = a.res != nullptr, acc = a.accumulate != 0;
   const float ps = a.post_scale;
   int ch = 0, rr = w;
   while (rr >= R) rr -= R, ++ch;                                // (uniform)
@@ -498,27 +497,41 @@ __device__ __forceinline__ void ds_inv_epilogue(const hsp_dftseg_args& a, const 
     const int c = I.c0 + ch;
     const float bz = a.bias ? a.bias[c] : 0.0f;
     char* const yb = reinterpret_cast<char*>(a.y + (int64_t)I.b * a.y_bs + (int64_t)c * a.y_cs + tb);
-    const char* const rb = has_res ? reinterpret_cast<const char*>(a.res + (int64_t)I.b * a.res_bs + (int64_t)c * a.res_cs + tb) : nullptr;
+    const char* const rb = RES ? reinterpret_cast<const char*>(a.res + (int64_t)I.b * a.res_bs + (int64_t)c * a.res_cs + tb) : nullptr;
     const float* const row = buf + ch * G.pitch;
     const int j0 = rr * (64 * U) + lane;
     vec_t r4[U], o4[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned off = (unsigned)(min(j0 + 64 * u, nel - 1) * (W * 4));
-      r4[u] = has_res ? *reinterpret_cast<const vec_t*>(rb + off) : vec_t(0.0f);
-      o4[u] = acc ? *reinterpret_cast<const vec_t*>(yb + off) : vec_t(0.0f);
+      if constexpr (RES) r4[u] = *reinterpret_cast<const vec_t*>(rb + off);
+      if constexpr (ACC) o4[u] = *reinterpret_cast<const vec_t*>(yb + off);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = j0 + 64 * u;
       if (j < nel) {
-        const vec_t v = *reinterpret_cast<const vec_t*>(row + W * j);
-        *reinterpret_cast<vec_t*>(yb + (unsigned)(j * (W * 4))) = (v + bz + r4[u] + o4[u]) * ps;
+        // ((corr + bias + res) + y) * post_scale in this order; a term that is not asked for is skipped (x + 0 and
+        // x * 1 are x: same values as the general form)
+        vec_t v = *reinterpret_cast<const vec_t*>(row + W * j) + bz;
+        if constexpr (RES) v += r4[u];
+        if constexpr (ACC) v += o4[u];
+        if (ps != 1.0f) v *= ps;
+        *reinterpret_cast<vec_t*>(yb + (unsigned)(j * (W * 4))) = v;
       }
     }
     rr += nw;
     while (rr >= R) rr -= R, ++ch;
   }
+}
+template <int W, int U>
+__device__ __forceinline__ void ds_inv_epilogue(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const float* buf,
+                                                int w, int nw, int lane, int tb, int tl) {
+  const bool has_res = a.res != nullptr, acc = a.accumulate != 0;   // (uniform: one of four instantiations runs)
+  if (has_res && acc) ds_inv_epilogue_t<W, U, true, true>(a, G, I, buf, w, nw, lane, tb, tl);
+  else if (has_res) ds_inv_epilogue_t<W, U, true, false>(a, G, I, buf, w, nw, lane, tb, tl);
+  else if (acc) ds_inv_epilogue_t<W, U, false, true>(a, G, I, buf, w, nw, lane, tb, tl);
+  else ds_inv_epilogue_t<W, U, false, false>(a, G, I, buf, w, nw, lane, tb, tl);
 }
 
 // The spectrum side of a thread: it recombines the bins kf(u) = 8 w + 4 half + u, u < 4, of one column, i.e. it loads
@@ -574,13 +587,21 @@ __device__ __forceinline__ void ds_inv_stash(float* dst, int kf0, const float (&
 // Scatter of a block's time samples into the LDS image of the output rows: accumulator register r of wave (eo, wh) is
 // sample i = 2 (32 wh + DS_ACC_ROW(r, half)) + eo of the column's segment; the first `hop` samples of a segment are
 // valid.  rp = the address of this lane's sample of register 0; no test against the tensor's end (see above).
-__device__ __forceinline__ void ds_inv_scatter(float* rp, int d, int i0, int hop, int wh, const ds_f32x16& acc, const ds_f32x16& acc2) {
+template <int D>
+__device__ __forceinline__ void ds_inv_scatter_d(float* rp, int d, int i0, int hop, int wh, const ds_f32x16& acc, const ds_f32x16& acc2) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int cr = (r & 3) + 8 * (r >> 2);
     // 2 (32 wh + cr + 4 half) + eo <= 63 < hop for every wh = 0 wave (hop >= 65: k <= 64); wh = 1 and r < 12: <= 95
-    if (wh == 0 || (r < 12 && hop >= 96) || i0 + 2 * cr < hop) rp[2 * d * cr] = acc[r] + acc2[r];
+    if (wh == 0 || (r < 12 && hop >= 96) || i0 + 2 * cr < hop) rp[2 * (D ? D : d) * cr] = acc[r] + acc2[r];
   }
+}
+// (the dilations of the AMP blocks -- 1, 3, 5 -- with the sample stride as an immediate offset of the LDS store)
+__device__ __forceinline__ void ds_inv_scatter(float* rp, int d, int i0, int hop, int wh, const ds_f32x16& acc, const ds_f32x16& acc2) {
+  if (d == 1) ds_inv_scatter_d<1>(rp, d, i0, hop, wh, acc, acc2);
+  else if (d == 3) ds_inv_scatter_d<3>(rp, d, i0, hop, wh, acc, acc2);
+  else if (d == 5) ds_inv_scatter_d<5>(rp, d, i0, hop, wh, acc, acc2);
+  else ds_inv_scatter_d<0>(rp, d, i0, hop, wh, acc, acc2);
 }
 
 __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_args a, const DsGeom G, int nbuf) {
@@ -679,7 +700,7 @@ __global__ __launch_bounds__(DS_MEM) void dftseg_inv_kernel(const hsp_dftseg_arg
     }
     const int tb = d * I.s0 * hop;                              // output index of row[0]
     const int tl = min(a.L - tb, d * I.S * hop);                // outputs of this chunk
-    if (vec0 && ((tb | tl) & 3) == 0) ds_inv_epilogue<4, 4>(a, G, I, lds, wave, 4, lane, tb, tl);
+    if (vec0 && ((tb | tl) & 3) == 0) ds_inv_epilogue<4, 8>(a, G, I, lds, wave, 4, lane, tb, tl);
     else ds_inv_epilogue<1, 4>(a, G, I, lds, wave, 4, lane, tb, tl);
     if (++it_c < nmine) {
       blk_c = 0;
@@ -898,6 +919,19 @@ int ds_check(const hsp_dftseg_args& a) {
   return 0;
 }
 
+// the persistent grid: the workgroups the device keeps resident at this LDS footprint
+int64_t ds_resident(size_t lds_bytes) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  const int per = (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+  return (int64_t)cus * per;
+}
+
 // Chunk geometry: the LARGEST even segment count whose stretch fits the LDS budget (the whole row at the Generator's
 // lengths: one staging per row -- smaller chunks were measured 1.1-2 x slower), then as many channel rows as still fit,
 // preferring a count that fills the last MFMA column block (112 columns of 16 rows x 7 segments leave an eighth of
@@ -923,31 +957,27 @@ DsGeom ds_geom(const hsp_dftseg_args& a, bool inverse) {
   cmax = cmax < 1 ? 1 : (cmax > 32 ? 32 : cmax);
   cmax = cmax > a.C ? a.C : cmax;
   const int quantum = inverse ? 32 : 64;                        // columns of one round of the MFMA waves
+  // (round 6) ... and a count whose items come out in whole ROUNDS of the persistent grid: 512 channels x 800 samples
+  // with 19 rows per item are 864 items on 512 resident workgroups -- a third of them walks one item while the others
+  // walk two (84 % of two rounds); 16 rows per item are 1 024 = two rounds exactly, for an eighth of the last column
+  // block left empty.  Score = column fill x round balance.
+  const int nchunk = (a.nseg + S - 1) / S;
   int best = cmax;
-  double best_fill = 0.0;
+  double best_score = 0.0;
   for (int cg = cmax; cg >= (cmax + 1) / 2; --cg) {
     const int ncols = cg * d * S;
     const double fill = (double)ncols / (quantum * ((ncols + quantum - 1) / quantum));
-    if (fill > best_fill + 1e-9) best_fill = fill, best = cg;
+    const size_t lds = inverse ? ((size_t)cg * G.pitch + 128 * 32) * sizeof(float) : ((size_t)cg * G.pitch + 64 + 32 + 4 * DA_SLICE) * sizeof(float);
+    const int64_t res = ds_resident(lds), items = (int64_t)a.B * ((a.C + cg - 1) / cg) * nchunk;
+    const double balance = (double)items / (double)(((items + res - 1) / res) * res);
+    const double score = fill * balance;
+    if (score > best_score + 1e-9) best_score = score, best = cg;
   }
   G.cg = best;
   G.bufsz = (G.cg * G.pitch + 3) & ~3;
   G.nchunk = (a.nseg + S - 1) / S;
   G.ngrp = (a.C + G.cg - 1) / G.cg;
   return G;
-}
-
-// the persistent grid: the workgroups the device keeps resident at this LDS footprint
-int64_t ds_resident(size_t lds_bytes) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  const int per = (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
-  return (int64_t)cus * per;
 }
 
 // The pair kernel's geometry; cg == 0: the pair cannot be fused (the caller runs the two launches)
@@ -967,6 +997,21 @@ DpGeom dp_geom(const hsp_dftseg_args& ai, const hsp_dftseg_args& af) {
   cg = cg > 32 ? 32 : cg;
   cg = cg > ai.C ? ai.C : cg;
   if (cg < 1) return G;
+  {
+    // (round 6) whole rounds of the one-workgroup-per-CU grid, as in ds_geom: 864 items of 19 rows on 256 workgroups are
+    // four rounds at 84 %, 1 024 items of 16 rows four rounds exactly
+    const int64_t res = ds_resident(160 * 1024);
+    int best = cg;
+    double best_score = 0.0;
+    for (int c = cg; c >= (cg + 1) / 2; --c) {
+      const int n1 = c * ai.dil * G.S1, n2 = c * af.dil * G.S2;
+      const double fill = 0.5 * ((double)n1 / (64 * ((n1 + 63) / 64)) + (double)n2 / (128 * ((n2 + 127) / 128)));
+      const int64_t items = (int64_t)ai.B * ((ai.C + c - 1) / c);
+      const double score = fill * (double)items / (double)(((items + res - 1) / res) * res);
+      if (score > best_score + 1e-9) best_score = score, best = c;
+    }
+    cg = best;
+  }
   G.cg = cg;
   G.ngrp = (ai.C + cg - 1) / cg;
   G.offB = cg * G.pitchA;
