@@ -42,7 +42,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define HSP_VERSION 101 /* 0.1.1: round 5 -- hsp_dftseg_args grew a field (prod3); hsp_cprod3_f32, hsp_cprod3_supported,
+#define HSP_VERSION 102 /* 0.1.2: round 6 -- hsp_dftseg_pair_f32 takes the pass-through form (inv->y / inv->res); 0.1.1: round 5
+                           * -- hsp_dftseg_args grew a field (prod3); hsp_cprod3_f32, hsp_cprod3_supported,
                            * hsp_dftseg_weight_spectrum_f32, hsp_dftseg_supported are new */
 #define HSP_EINVAL (-1)
 
@@ -505,7 +506,13 @@ int hsp_dftseg_tables_f32(float* fwd, float* inv); /* host buffers of HSP_DFTSEG
  * no residual / running sum / post_scale), `fwd` the forward transform of c2's input (xf = c2's spectrum to write, dft =
  * the forward table, act_* = a2, required); same B, C, L.  y of `inv` and x of `fwd` are not read: the tensor between
  * the convs exists in LDS only.  hsp_dftseg_pair_supported: 1 if the pair fits (both unchunked, two row stretches in one
- * CU's LDS), else 0 and the caller runs hsp_dftseg_inv_f32 + hsp_dftseg_fwd_f32. */
+ * CU's LDS), else 0 and the caller runs hsp_dftseg_inv_f32 + hsp_dftseg_fwd_f32.
+ * Pass-through form (round 6; version 102): `inv->y` given (with `inv->res` or without) -- the tensor between the two
+ * transforms IS needed elsewhere: the seam between two iterations of an AMP block (hierspeechpp_speechsynthesizer.py:
+ * 380-384: x = c2(...) + x; xt = a1'(x) ...), where x_new = inverse(c2's product) + bias + res is the residual of the next
+ * iteration.  The launch then writes x_new to `inv->y` (16-B addressable rows) and transforms act(x_new) for the next
+ * conv: the inverse launch, the forward launch and one read of x_new become one launch.  Same arithmetic in the same
+ * order as the two launches. */
 int hsp_dftseg_pair_supported(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd);
 int hsp_dftseg_pair_f32(const hsp_dftseg_args* inv, const hsp_dftseg_args* fwd, void* stream);
 

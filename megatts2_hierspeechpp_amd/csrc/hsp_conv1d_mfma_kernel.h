@@ -1170,7 +1170,10 @@ int launch_one(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   const int64_t tiles = (int64_t)((a.M + C::BM - 1) / C::BM) * ((a.ncols + C::BN - 1) / C::BN) * a.B;
   // (same box: 42.4 -> 39.3 us per launch, step 81.05 -> 80.77 ms; beyond 512 tiles the deep chunk wins again: 67.8 vs 69.7)
   // (tuning bit 1 << 26: the half-CU chunk for ANY launch of up to 512 tiles, so that launches of different streams can share a CU)
-  const bool two_per_cu = C::MINW * 256 >= 2 * C::THREADS || ((tiles > 256 || HSP_DBG(a, 1 << 26)) && tiles <= 512 && !HSP_DBG(a, 1 << 21));
+  // (tuning bit 1 << 29, round 6 / VERDICT r05 item 8: a k <= 3 conv takes the deepest chunk the whole CU can stage -- twice
+  // the MFMAs per barrier and window DMA, ONE workgroup per CU; measured in profiles/r06_k3_deep_chunk.txt)
+  const bool deep_k3 = HSP_DBG(a, 1 << 29) && a.K <= 3;
+  const bool two_per_cu = !deep_k3 && (C::MINW * 256 >= 2 * C::THREADS || ((tiles > 256 || HSP_DBG(a, 1 << 26)) && tiles <= 512 && !HSP_DBG(a, 1 << 21)));
   int lkc = pick_lkc<C>(a, two_per_cu ? kLdsTarget : kMaxLdsBytes);
   if (lkc < 0) lkc = pick_lkc<C>(a, kMaxLdsBytes);
   if (lkc < 0) return HSP_EINVAL;

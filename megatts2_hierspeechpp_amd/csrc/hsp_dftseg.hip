@@ -484,7 +484,9 @@ __global__ __launch_bounds__(DS_MEM) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // Epilogue of the conv this replaces, y = ((corr + bias + res) [+ y]) * post_scale, out of the LDS stretch of an item.
 // A UNIT = 64 U consecutive W-float vectors of one row; wave w of nw takes units w, w + nw, ...: the row's base addresses
 // (y, res) are wave-uniform 64-bit values, a lane adds one 32-bit byte offset per vector.
-template <int W, int U, bool RES, bool ACC>
+// KEEP: the finished samples also go back into the stretch (the pair kernel's pass-through form: the activation of the
+// next conv reads them there)
+template <int W, int U, bool RES, bool ACC, bool KEEP = false>
 __device__ __forceinline__ void ds_inv_epilogue_t(const hsp_dftseg_args& a, const DsGeom& G, const DsItem& I, const float* buf,
                                                   int w, int nw, int lane, int tb, int tl) {
   typedef float vec_t __attribute__((ext_vector_type(W)));
@@ -518,6 +520,7 @@ __device__ __forceinline__ void ds_inv_epilogue_t(const hsp_dftseg_args& a, cons
         if constexpr (ACC) v += o4[u];
         if (ps != 1.0f) v *= ps;
         *reinterpret_cast<vec_t*>(yb + (unsigned)(j * (W * 4))) = v;
+        if constexpr (KEEP) *reinterpret_cast<vec_t*>(const_cast<float*>(row) + W * j) = v;
       }
     }
     rr += nw;
@@ -846,6 +849,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       else step1(v1, q1);
       odd = !odd;
     }
+    // ---------------- phase 1.5 (pass-through form, round 6: ai.y given): the first conv's whole epilogue -- bias + residual --
+    // happens here, its output leaves for HBM (it is the residual of the NEXT iteration: x = xt + x,
+    // hierspeechpp_speechsynthesizer.py:384) and stays in A for the activation of the next conv
+    const bool through = ai.y != nullptr;
+    if (through) {
+      const DsGeom Ga = {G.cg, G.S1, G.pitchA, G.ngrp, 1, 0};
+      if (ai.res) ds_inv_epilogue_t<4, 4, true, false, true>(ai, Ga, I, sA, wave, 8, lane, 0, ai.L);
+      else ds_inv_epilogue_t<4, 4, false, false, true>(ai, Ga, I, sA, wave, 8, lane, 0, ai.L);
+      ds_barrier();
+    }
     // ---------------- phase 2: A -> act -> B
     {
       DsStage sg;
@@ -859,7 +872,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int sI = wave; sI < da.nsegs; sI += 8) {
         const int ch = sI / da.nsg, p0 = da.pa4 + DA_SEG * (sI - ch * da.nsg);
         const ds_f32x4 rv = *reinterpret_cast<const ds_f32x4*>(sA + ch * G.pitchA + hsp_clampi(p0 - 8 + 4 * lane, 0, af.L - 4));
-        da_segment(af, Gf, I, sg, da, sI, lane, rv, slice, sB, flt, ai.bias ? ai.bias[I.c0 + ch] : 0.0f);
+        da_segment(af, Gf, I, sg, da, sI, lane, rv, slice, sB, flt, (ai.bias && !through) ? ai.bias[I.c0 + ch] : 0.0f);
       }
       for (int ch = 0; ch < I.ncg; ++ch) {                      // the conv's zero padding on either side
         float* row = sB + ch * G.pitchB + sg.sh;
@@ -984,7 +997,12 @@ DsGeom ds_geom(const hsp_dftseg_args& a, bool inverse) {
 DpGeom dp_geom(const hsp_dftseg_args& ai, const hsp_dftseg_args& af) {
   DpGeom G = {};
   if (ds_check(ai) || ds_check(af)) return G;
-  if (ai.B != af.B || ai.C != af.C || ai.L != af.L || ai.res || ai.accumulate || ai.post_scale != 1.0f) return G;
+  if (ai.B != af.B || ai.C != af.C || ai.L != af.L || ai.accumulate || ai.post_scale != 1.0f) return G;
+  if (ai.res && !ai.y) return G;                                // a residual belongs to the pass-through form (ai.y given)
+  if (ai.y) {                                                   // ... whose epilogue moves 16-B vectors
+    if (((ai.L | (int)ai.y_bs | (int)ai.y_cs) & 3) || (reinterpret_cast<uintptr_t>(ai.y) & 15)) return G;
+    if (ai.res && ((((int)ai.res_bs | (int)ai.res_cs) & 3) || (reinterpret_cast<uintptr_t>(ai.res) & 15))) return G;
+  }
   if (!af.act_alpha_exp || !af.act_beta_inv || !af.act_filt || (af.L & 3)) return G;
   if (af.xf_bs * 64 * 4 > 0xffffffffll) return G;
   const int hop1 = DS_N - (ai.k - 1), hop2 = DS_N - (af.k - 1);

@@ -156,12 +156,72 @@ class AMPBlock1(nn.Module):
         """``before_last``: an event the current stream waits on before the last launch (the one
         that accumulates into the shared ``out`` of the stage)."""
         n = len(self.convs1)
+        if FFT_THROUGH and fft_chain_ok(self, x):
+            return amp_block_fft_chain(self, x, out=out, accumulate=accumulate, post_scale=post_scale, before_last=before_last)
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             last = i == n - 1
             x = amp_pair(c1, c2, self.activations[2 * i], self.activations[2 * i + 1], x,
                          before_last=before_last if last else None, res=x, out=out if last else None,
                          accumulate=accumulate and last, post_scale=post_scale if last else 1.0)
         return x
+
+
+# (round 6, VERDICT r05 item 1a)  A whole AMP block in the frequency domain as ONE chain of spectra: the seam between two
+# iterations -- inverse of c2's product + bias + residual -> x_new, then a1'(x_new) -> forward for the next c1 -- is one
+# launch too (hsp_dftseg_pair_f32, pass-through form: x_new is written once and never read back by a transform): 7 transform
+# launches per block instead of 9.  MEASURED AND NOT KEPT AS THE DEFAULT: same-box 56.84 (per-iteration form, amp_pair) against
+# 57.10 ms per 32 x 4 s step with the chain (profiles/r06_ab_fft_through.json) -- the pair kernel runs its phases one after
+# the other on one workgroup per CU, and the seam's residual read and x_new write join a phase that nothing overlaps, while
+# the separate inverse and forward launches run two workgroups per CU each.  HSP_FFT_THROUGH=1 switches it on; the parity
+# tests run both forms (tests/test_gpu_parity.py::test_amp_block_as_one_chain_of_spectra).
+FFT_THROUGH = os.environ.get("HSP_FFT_THROUGH", "0") == "1"
+
+
+def fft_chain_ok(block, x) -> bool:
+    """Every conv of the block takes the frequency-domain form for an input like x, every pair and every seam fuses."""
+    if not (FFT_PAIR and fft_act(x)) or x.shape[1] <= FUSE_ACT_MAX_CHANNELS:
+        return False
+    key = (x.shape[0], x.shape[2], x.stride(0), x.stride(1), x.data_ptr() & 15)
+    memo = block.__dict__.setdefault("_chain_ok", {})
+    ok = memo.get(key)
+    if ok is None:
+        n = len(block.convs1)
+        ok = all(fft_wins(c, x) for c in list(block.convs1) + list(block.convs2)) and \
+            all(block.convs1[i].fft_pair_ok(block.convs2[i], x) for i in range(n)) and \
+            all(block.convs2[i].fft_through_ok(block.convs1[i + 1], x) for i in range(n - 1))
+        if len(memo) >= 256:
+            memo.clear()
+        memo[key] = ok
+        return ok
+    # (fft_wins also guards the capture-before-first-use case: ask it again, it is cheap once the geometry is cached)
+    return ok and all(fft_wins(c, x) for c in list(block.convs1) + list(block.convs2))
+
+
+def amp_block_fft_chain(block, x, *, out=None, accumulate=False, post_scale=1.0, before_last=None):
+    """AMPBlock1.forward (hierspeechpp_speechsynthesizer.py:377-386) with every conv in the frequency domain:
+    forward(a1(x)) -> [product c1 -> inverse + a2 + forward -> product c2 -> inverse + residual + a1' + forward] x (n - 1)
+    -> product c1 -> inverse + a2 + forward -> product c2 -> inverse with the block's epilogue."""
+    n = len(block.convs1)
+    B, Cc, Lx = x.shape
+    acts = block.activations
+    hook = hip_layers.LAUNCH_HOOK
+    xf, e_first = block.convs1[0]._fft_forward(x, acts[0])
+    for i in range(n):
+        c1, c2 = block.convs1[i], block.convs2[i]
+        xf2, _ = c1._fft_pair_launch(c2, c1._fft_product(xf), B, Lx, acts[2 * i + 1], x)
+        yf2 = c2._fft_product(xf2)
+        if i < n - 1:
+            x_new = torch.empty_like(x)
+            xf, _ = c2._fft_pair_launch(block.convs1[i + 1], yf2, B, Lx, acts[2 * i + 2], x, res=x, y=x_new)
+            x = x_new
+        else:
+            out, e_last = c2._fft_inverse(yf2, B, Lx, res=x, out=out, accumulate=accumulate, post_scale=post_scale,
+                                          before_inverse=before_last)
+    if hook is not None:
+        ks = sum(c.k for c in list(block.convs1) + list(block.convs2))
+        nio = 2 * n + 1 + 2 * bool(accumulate)            # every iteration reads and writes x once more than a lone conv
+        hook("hsp_fftconv", 2 * B * Cc * Cc * ks * Lx, 4 * B * Cc * Lx * nio + 4 * ks * Cc * Cc, e_first, e_last, 2 * n)
+    return out
 
 
 def amp_pair(c1, c2, a1, a2, x, *, form=None, before_last=None, **kw):

@@ -620,6 +620,53 @@ class Conv1d(_ConvBase):
         ia.xf_bs, fa.xf_bs = 2 * self.cin * ia.Np, 2 * self.cin * fa.Np
         return bool(L.lib().hsp_dftseg_pair_supported(C.byref(ia), C.byref(fa)))
 
+    def _fft_pair_launch(self, second, yf, B, Lx, act_second, like, res=None, y=None):
+        """ONE launch (hsp_dftseg_pair_f32): inverse transform of this conv's product ``yf`` + bias [+ ``res``, the result
+        written to ``y``: the pass-through form] -> ``act_second`` -> forward transform for ``second``.  Returns second's
+        spectrum and the launch's (start, end) events when a LAUNCH_HOOK is set."""
+        Cc = self.cin
+        ia = self._fft_inverse_args(yf, B, Lx)
+        fa = second._fft_args(B, Lx)
+        xf2 = _spectrum(Cc, fa.Np, yf.device)
+        fa.xf, fa.xf_bs, fa.dft = L.fptr(xf2), xf2.stride(0), L.fptr(_dft_tables(yf.device)[0])
+        self._fft_set_act(fa, like, act_second)
+        if y is not None:
+            assert y.shape == (B, Cc, Lx) and y.stride(2) == 1
+            ia.y, ia.y_bs, ia.y_cs = L.fptr(y), y.stride(0), y.stride(1)
+            if res is not None:
+                assert res.shape == y.shape and res.stride(2) == 1
+                ia.res, ia.res_bs, ia.res_cs = L.fptr(res), res.stride(0), res.stride(1)
+        else:
+            assert res is None
+        hook, ev = LAUNCH_HOOK, (None, None)
+        if hook is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        L.check(L.lib().hsp_dftseg_pair_f32(C.byref(ia), C.byref(fa), L.stream_ptr()), "hsp_dftseg_pair_f32")
+        if hook is not None:
+            ev[1].record()
+            nio = 0 if y is None else 1 + (res is not None)
+            hook("hsp_dftseg_pair_f32", 2 * 2 * 64 * 64 * B * Cc * (ia.dil * ia.nseg + fa.dil * fa.nseg),
+                 4 * 128 * Cc * (ia.Np + fa.Np) + 4 * B * Cc * Lx * nio, ev[0], ev[1], None)
+        return xf2, ev
+
+    def fft_through_ok(self, nxt, x) -> bool:
+        """Can the inverse transform of this conv WITH its residual epilogue be fused with the activation and the forward
+        transform of ``nxt`` -- the seam between two iterations of an AMP block (hsp_dftseg_pair_f32, pass-through form)?"""
+        if not self.__dict__.get("_fft") or not nxt.__dict__.get("_fft") or nxt.cin != self.cin or x.shape[2] % 4:
+            return False
+        if x.stride(2) != 1 or (x.stride(0) | x.stride(1)) & 3 or x.data_ptr() & 15:
+            return False
+        B, _, Lx = x.shape
+        ia, fa = self._fft_args(B, Lx), nxt._fft_args(B, Lx)
+        dummy = L.fptr(_zeros(x.device))
+        ia.xf = ia.dft = fa.xf = fa.dft = fa.act_alpha_exp = fa.act_beta_inv = fa.act_filt = dummy
+        ia.y = ia.res = L.fptr(x)                                # geometry + alignment of rows like x's
+        ia.y_bs = ia.res_bs = x.stride(0)
+        ia.y_cs = ia.res_cs = x.stride(1)
+        ia.xf_bs, fa.xf_bs = 2 * self.cin * ia.Np, 2 * self.cin * fa.Np
+        return bool(L.lib().hsp_dftseg_pair_supported(C.byref(ia), C.byref(fa)))
+
     def forward_fft_pair(self, second, x, *, act_first, act_second, res=None, out=None, accumulate=False, post_scale=1.0,
                          before_inverse=None):
         """second(act_second(self(act_first(x)))) [+ res ...] with both convs in the frequency domain and the tensor between
@@ -630,20 +677,8 @@ class Conv1d(_ConvBase):
         B, Cc, Lx = x.shape
         xf, e_first = self._fft_forward(x, act_first)
         yf = self._fft_product(xf)
-        ia = self._fft_inverse_args(yf, B, Lx)
-        fa = second._fft_args(B, Lx)
-        xf2 = _spectrum(Cc, fa.Np, x.device)
-        fa.xf, fa.xf_bs, fa.dft = L.fptr(xf2), xf2.stride(0), L.fptr(_dft_tables(x.device)[0])
-        self._fft_set_act(fa, x, act_second)
         hook = LAUNCH_HOOK
-        if hook is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        L.check(L.lib().hsp_dftseg_pair_f32(C.byref(ia), C.byref(fa), L.stream_ptr()), "hsp_dftseg_pair_f32")
-        if hook is not None:
-            e1.record()
-            hook("hsp_dftseg_pair_f32", 2 * 2 * 64 * 64 * B * Cc * (ia.dil * ia.nseg + fa.dil * fa.nseg),
-                 4 * 128 * Cc * (ia.Np + fa.Np), e0, e1, None)
+        xf2, _ = self._fft_pair_launch(second, yf, B, Lx, act_second, x)
         yf2 = second._fft_product(xf2)
         out, e_last = second._fft_inverse(yf2, B, Lx, res=res, out=out, accumulate=accumulate, post_scale=post_scale,
                                           before_inverse=before_inverse)

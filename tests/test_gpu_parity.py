@@ -1875,6 +1875,42 @@ def test_golden_frequency_domain_forced(name, device, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C_,k,L", [(128, 11, 1600), (128, 7, 4000), (256, 11, 800)])
+def test_amp_block_as_one_chain_of_spectra(C_, k, L, device, monkeypatch):
+    """hsp_dftseg_pair_f32's pass-through form (round 6): a whole AMPBlock1 (hierspeechpp_speechsynthesizer.py:377-386) as one
+    chain of spectra -- the seam between two iterations (inverse of c2's product + bias + residual -> x_new written once,
+    a1'(x_new) -> forward for the next c1) is ONE launch -- against the per-iteration form of the same block (same arithmetic
+    in the same order: equal up to the conv-form tolerance, in practice bit for bit) and against torch float64."""
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from megatts2_hierspeechpp_amd import hip_layers
+    g = torch.Generator().manual_seed(7 * C_ + k)
+    blk = hss.AMPBlock1(C_, k, (1, 3, 5), activation="snakebeta")
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            p_.copy_(0.3 * torch.randn(p_.shape, generator=g))
+        for c in list(blk.convs1) + list(blk.convs2):
+            c.weight_g.copy_(0.3 + 0.4 * torch.rand(c.weight_g.shape, generator=g))
+    hip_layers.finalize(blk, device)
+    x = torch.randn(3, C_, L, generator=g).to(device)
+    monkeypatch.setattr(hss, "FFT_MIN_COLS", 0)
+    kinds = []
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", lambda kind, *a: kinds.append(kind))
+    monkeypatch.setattr(hss, "FFT_THROUGH", False)
+    y_iter = blk(x)
+    n_iter = kinds.count("hsp_dftseg_pair_f32"), kinds.count("hsp_dftseg_inv_f32"), kinds.count("hsp_dftseg_fwd_f32")
+    kinds.clear()
+    monkeypatch.setattr(hss, "FFT_THROUGH", True)
+    y_chain = blk(x)
+    n_chain = kinds.count("hsp_dftseg_pair_f32"), kinds.count("hsp_dftseg_inv_f32"), kinds.count("hsp_dftseg_fwd_f32")
+    monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", None)
+    assert n_iter == (3, 3, 3) and n_chain == (5, 1, 1), (n_iter, n_chain)      # 9 -> 7 transform launches
+    assert float((y_chain - y_iter).abs().max()) <= 1e-6 * max(1.0, float(y_iter.abs().max()))
+    monkeypatch.setattr(hss, "FFT_CONV", False)
+    y_direct = blk(x)
+    _close(y_chain.cpu().numpy(), y_direct.cpu().numpy(), f"AMP block C {C_} k {k}: chain of spectra vs direct convs")
+
+
+@pytest.mark.gpu
 def test_frequency_domain_conv_dynamic_range(device):
     """A 0 dB burst beside -60 dB noise in one 128-channel row.  An overlap-save segment carries rounding errors that scale
     with ITS loudest sample, so the quiet outputs that share a 128-sample segment with the burst see an error relative to

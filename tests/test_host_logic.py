@@ -149,7 +149,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.hsp_version() == 101 and lib.hsp_arch() == b"gfx950"
+    assert lib.hsp_version() == 102 and lib.hsp_arch() == b"gfx950"
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
