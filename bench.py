@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_PROFILE = "r05_traffic.json"   # tools/pmc_traffic.sh + tools/pmc_summarize.py; quoted only when it matches this build
+TRAFFIC_PROFILE = "r06_traffic.json"   # tools/pmc_traffic.sh + tools/pmc_summarize.py; quoted only when it matches this build
 METRIC = "16kHz audio samples/sec (whole node) + RTF, HierSpeech++ vocoder batch=32"
 
 VOC_CFG = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3,

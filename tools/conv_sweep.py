@@ -17,6 +17,9 @@ ap.add_argument("--shapes", nargs="+", default=["256:4000:3", "256:4000:11", "12
                                                 "512:800:11", "64:32000:3", "64:32000:11", "32:64000:3", "32:64000:11"])
 ap.add_argument("--debug", nargs="+", type=int, default=[0])
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--rotate", type=int, default=1,
+                help="(round 6) cycle the launches over this many separate (x, res, out) buffer sets, so that a launch finds "
+                     "neither its input nor its residual in the Infinity Cache / L2 -- what a conv meets inside the step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -31,9 +34,9 @@ for shp in a.shapes:
     conv.weight.data.normal_(0, 0.05)
     conv.bias.data.normal_(0, 0.1)
     hip_layers.finalize(conv, dev)
-    x = torch.randn(B, C_, L, device=dev)
-    res = torch.randn(B, Co, L, device=dev) if res_on else None
-    out = torch.empty(B, Co, L, device=dev)
+    sets = [(torch.randn(B, C_, L, device=dev), torch.randn(B, Co, L, device=dev) if res_on else None,
+             torch.empty(B, Co, L, device=dev)) for _ in range(a.rotate)]
+    x, res, out = sets[0]
     fl = 2.0 * B * C_ * Co * K * L
     row = []
     for dbg in a.debug:
@@ -47,7 +50,8 @@ for shp in a.shapes:
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(a.reps):
+        for i in range(a.reps):
+            x, res, out = sets[i % a.rotate]
             conv(x, res=res, out=out)
         e1.record()
         torch.cuda.synchronize()

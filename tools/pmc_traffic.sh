@@ -1,7 +1,7 @@
 # HBM traffic of one bench step from the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE cannot share a
 # pass; rocprofv3 wraps python3 bench.py directly -- no env / shell hop behind `--`).  Run on the GPU box:
 #     bash tools/pmc_traffic.sh          then, back in the build container:
-#     python tools/pmc_summarize.py gpurun_out profiles/r05_traffic.json
+#     python tools/pmc_summarize.py gpurun_out profiles/r06_traffic.json
 # The step's own stand-alone activation launches (act1d_seg_kernel: exactly one float4 read and one float4 write per
 # element, 16-B lanes like the conv kernel's LDS-DMA) are the calibration for FETCH_SIZE -- a kernel whose bytes are
 # known independently of the kernel being judged.
