@@ -104,6 +104,39 @@ def test_convtr_pack_map_is_the_polyphase_identity():
         assert np.abs(y - ref).max() < 1e-5, (k, u)
 
 
+def test_flip_folds_into_the_next_coupling_layers_packed_weights():
+    """The algebra behind modules.ResidualCouplingLayer_Transformer_simple.set_flipped (round 6): a coupling layer called on
+    flip(x) (modules.py:270-277, hierspeechpp_speechsynthesizer.py:80-86) equals flip of the same layer called on x with
+    `pre` reading the OTHER half through reversed input columns and `post` updating the first half through reversed rows
+    and bias -- checked on the CPU oracle's own coupling layer (float64), not on the GPU path (the `flow` golden does that)."""
+    from oracle import hsp_oracle as O
+    g = torch.Generator().manual_seed(11)
+    C_, Hd, T = 8, 16, 9
+    name = "cl"
+    sd = {}
+    def rnd(*shape): return torch.randn(*shape, generator=g, dtype=torch.float64)
+    sd[f"{name}.pre.weight"], sd[f"{name}.pre.bias"] = rnd(Hd, C_ // 2, 1), rnd(Hd)
+    sd[f"{name}.post.weight"], sd[f"{name}.post.bias"] = rnd(C_ // 2, Hd, 1), rnd(C_ // 2)
+    x = rnd(2, C_, T)
+    mask = (torch.rand(2, 1, T, generator=g) > 0.2).double()
+    half = C_ // 2
+    # the reference's order with zero DiT blocks in between (their input and output live in the hidden space: untouched by the fold)
+    want = O.coupling_reverse(sd, name, torch.flip(x, [1]), mask, None, n_layers=0)
+    # the folded layer on the un-flipped tensor
+    pre_w = sd[f"{name}.pre.weight"].flip(1)
+    post_w, post_b = sd[f"{name}.post.weight"].flip(0), sd[f"{name}.post.bias"].flip(0)
+    h = torch.nn.functional.conv1d(x[:, half:], pre_w, sd[f"{name}.pre.bias"]) * mask
+    m = torch.nn.functional.conv1d(h, post_w, post_b) * mask
+    got = torch.cat([(x[:, :half] - m) * mask, x[:, half:]], 1)
+    assert torch.allclose(torch.flip(got, [1]), want, rtol=0, atol=1e-12)
+    # and the block's bookkeeping: with n_flows = 4 the layers 3 and 1 work on the reversed axis, no Flip is left over
+    from megatts2_hierspeechpp_amd.hierspeechpp_speechsynthesizer import ResidualCouplingBlock_Transformer
+    blk = ResidualCouplingBlock_Transformer(192, 192, 5, 1, 3, gin_channels=256)
+    assert [blk.flows[2 * i].flipped for i in range(4)] == [False, True, False, True]
+    assert [blk.flows[2 * i].pre.__dict__.get("_flip_in", False) for i in range(4)] == [False, True, False, True]
+    assert [blk.flows[2 * i].post.__dict__.get("_flip_out", False) for i in range(4)] == [False, True, False, True]
+
+
 def test_arena_layout_is_deterministic_and_aligned():
     """Every rank lays the arena out identically (the broadcast relies on it)."""
     from megatts2_hierspeechpp_amd.hip_layers import HipLayer, WeightArena
