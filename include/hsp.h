@@ -180,6 +180,23 @@ typedef struct hsp_conv1d_args {
    * hsp_dftseg_*_f32 below), where the batch index is the frequency BIN and every bin has its own [Cin][M] matrix.
    * The implicit-GEMM conv kernel only (the token GEMMs refuse it). */
   int64_t w_bs;
+  /* Modulated input LayerNorm (round 6; with ln_c1, on the block token GEMM only -- any other launch that carries one of
+   * these fields is refused with HSP_EINVAL): the adaLN form of a DiT block's first half,
+   *   qkv = W ((LN(x) * mask) * (1 + scale_b) + shift_b) + bias        (modules.py:346-347,406-409: norm1 has no affine,
+   *                                                                     scale / shift differ per UTTERANCE b)
+   * as ONE launch on the un-normalised x:  v = rstd[t] mask[b, t] (acc[m, t] - mean[t] c1_b[m]) + bias_b[m]  with
+   *   acc = W diag(1 + scale_b) x          ln_scale[b * ln_scale_bs + ci] = scale_b[ci]: the kernel multiplies the staged
+   *                                        input fragments by (1 + scale) on their way into the MFMA
+   *   c1_b[m] = sum_ci W[m][ci] (1 + scale_b[ci])      = ln_c1[b * ln_c1_bs + m]        (ln_c1_bs = 0: one vector for all b)
+   *   bias_b[m] = sum_ci W[m][ci] shift_b[ci] + bias[m] = cbias[b * cbias_bs + m]       (bias NULL)
+   *   ln_mask[b * ln_mask_bs + t]: the 0 / 1 column mask applied to the normalised input (NULL = none).
+   * c1_b and bias_b are linear in the conditioning vector: the caller gets them as extra rows of the one GEMM that
+   * produces scale_b / shift_b (hip_layers / modules.DiTConVBlock).  Cin <= 1024.  NULL ln_scale = plain ln_c1 form. */
+  const float* ln_scale;
+  int64_t ln_scale_bs;
+  int64_t ln_c1_bs;
+  const float* ln_mask;
+  int64_t ln_mask_bs;
 } hsp_conv1d_args;
 
 /* MFMA (v_mfma_f32_32x32x2_f32, exact fp32) path; stride must be 1, M % 4 == 0.  Behind this entry point: the

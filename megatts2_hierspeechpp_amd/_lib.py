@@ -45,6 +45,7 @@ class Conv1dArgs(C.Structure):
         ("ln_c1", _fp), ("ln_eps", C.c_float),
         ("split_row", C.c_int32), ("accumulate2", C.c_int32), ("mask_mode2", C.c_int32), ("y2", _fp),
         ("y2_bs", C.c_int64), ("y2_cs", C.c_int64), ("res_ts", C.c_int64), ("w_bs", C.c_int64),
+        ("ln_scale", _fp), ("ln_scale_bs", C.c_int64), ("ln_c1_bs", C.c_int64), ("ln_mask", _fp), ("ln_mask_bs", C.c_int64),
     ]
 
 

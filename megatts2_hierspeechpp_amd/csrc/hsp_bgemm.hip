@@ -90,14 +90,22 @@ __device__ __forceinline__ void bg_read(float (&A)[bg_gs(TM, TN) * TM], float (&
 // waves that share a column range split its two blocks between them when TN == 2: the fp32 MFMAs run on the VALU's
 // own lanes, so every statistics instruction is paid in matrix time).  TAIL: the stage holds fewer than 48 channels;
 // the rows beyond K are staged as zeros and must not enter the column's sums.
-template <int TM, int TN, bool LN, int SEL, bool TAIL, int G = 0>
+// MOD (round 6, hsp.h ln_scale): the B fragments are multiplied by (1 + scale_b[channel]) on their way into the MFMA --
+// `sl` = this stage's 48 factors in LDS (already offset by the lane's half: channel 2 k + half of k-step k); the column
+// statistics keep the unscaled values.
+template <int TM, int TN, bool LN, int SEL, bool TAIL, bool MOD = false, int G = 0>
 __device__ __forceinline__ void bg_stage(bg_f32x16 (&acc)[TM * TN], float (&A0)[bg_gs(TM, TN) * TM],
                                          float (&B0)[bg_gs(TM, TN) * TN], float (&A1)[bg_gs(TM, TN) * TM],
                                          float (&B1)[bg_gs(TM, TN) * TN], bg_lptr wa, bg_lptr xa, float& s1, float& s2,
-                                         float pivot, int rows2) {
+                                         float pivot, int rows2, bg_lptr sl = nullptr) {
   constexpr int GS = bg_gs(TM, TN), NG = BG_KS / (2 * GS);
   if constexpr (G < NG) {
     if constexpr (G + 1 < NG) bg_read<TM, TN, G + 1>(A1, B1, wa, xa);
+    float sv[GS];
+    if constexpr (MOD) {
+#pragma unroll
+      for (int i = 0; i < GS; ++i) sv[i] = sl[2 * (GS * G + i)];
+    }
 #pragma unroll
     for (int i = 0; i < GS; ++i) {
       if constexpr (LN) {
@@ -109,11 +117,13 @@ __device__ __forceinline__ void bg_stage(bg_f32x16 (&acc)[TM * TN], float (&A0)[
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm * TN + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i * TM + tm], B0[i * TN + tn], acc[tm * TN + tn], 0, 0, 0);
+        for (int tn = 0; tn < TN; ++tn) {
+          const float bv = MOD ? B0[i * TN + tn] * sv[i] : B0[i * TN + tn];
+          acc[tm * TN + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i * TM + tm], bv, acc[tm * TN + tn], 0, 0, 0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
-    bg_stage<TM, TN, LN, SEL, TAIL, G + 1>(acc, A1, B1, A0, B0, wa, xa, s1, s2, pivot, rows2);
+    bg_stage<TM, TN, LN, SEL, TAIL, MOD, G + 1>(acc, A1, B1, A0, B0, wa, xa, s1, s2, pivot, rows2, sl);
   }
 }
 
@@ -245,10 +255,11 @@ __device__ __forceinline__ void bg_epilogue_ext(const hsp_conv1d_args& a, const 
 template <int N>
 __device__ __forceinline__ void bg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TM, int TN, bool LN, bool EXT>
+template <int TM, int TN, bool LN, bool EXT, bool MOD = false>
 __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, int n_mt, int n_nt, int per_xcd,
                                                        int total) {
   using C = BgCfg<TM, TN>;
+  static_assert(!MOD || (LN && !EXT), "the modulated form is a fused-LayerNorm form");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // logical tile id: XCD x (workgroups x, x + 8, ...) takes ids [x * per_xcd, (x + 1) * per_xcd)
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -368,7 +379,14 @@ __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, 
     const int mc = min(mw + lane, a.Cout - 1);
     bvl = a.bias ? a.bias[mc] : 0.0f;
     if (a.cbias) bvl += a.cbias[(int64_t)b * a.cbias_bs + mc];
-    if constexpr (LN) c1l = a.ln_c1[mc];
+    if constexpr (LN) c1l = a.ln_c1[(int64_t)b * a.ln_c1_bs + mc];
+  }
+  // MOD: (1 + scale_b[c]) of this tile's utterance behind the stages (1 beyond K: those rows are staged as zeros);
+  // the first stage barrier below publishes it
+  float* const scl = lds + C::NST * C::STAGE;
+  if constexpr (MOD) {
+    const float* sp = a.ln_scale + (int64_t)b * a.ln_scale_bs;
+    for (int c = tid; c < nstage * BG_KS; c += 256) scl[c] = c < K ? 1.0f + sp[c] : 1.0f;
   }
   constexpr int GS = bg_gs(TM, TN);
   // LayerNorm statistics: this wave sums ONE of its column blocks (TN == 2: wave wm takes block wm, its partner of
@@ -394,11 +412,13 @@ __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, 
         bg_stage<TM, TN, false, 0, false>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, 0);
         s2 = 1.0f;
       } else if (rows == BG_KS) {
-        if (sel) bg_stage<TM, TN, true, TN - 1, false>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, 0);
-        else bg_stage<TM, TN, true, 0, false>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, 0);
+        const bg_lptr sl = (bg_lptr)(scl + s * BG_KS + half);
+        if (sel) bg_stage<TM, TN, true, TN - 1, false, MOD>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, 0, sl);
+        else bg_stage<TM, TN, true, 0, false, MOD>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, 0, sl);
       } else {
-        if (sel) bg_stage<TM, TN, true, TN - 1, true>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, rows >> 1);
-        else bg_stage<TM, TN, true, 0, true>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, rows >> 1);
+        const bg_lptr sl = (bg_lptr)(scl + s * BG_KS + half);
+        if (sel) bg_stage<TM, TN, true, TN - 1, true, MOD>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, rows >> 1, sl);
+        else bg_stage<TM, TN, true, 0, true, MOD>(acc, A0, B0, A1, B1, wa, xa, s1, s2, pivot, rows >> 1, sl);
       }
     }
     if (s + C::NST < nstage) bg_barrier();                // B_s
@@ -418,7 +438,10 @@ __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, 
     const float dm = t1 / (float)K;
     const float mu = pivot + dm;
     const float var = fmaxf(t2 / (float)K - dm * dm, 0.0f);
-    const float rs = 1.0f / sqrtf(var + a.ln_eps);
+    float rs = 1.0f / sqrtf(var + a.ln_eps);
+    if constexpr (MOD) {                                  // the column mask of the normalised input (hsp.h ln_mask)
+      if (a.ln_mask) rs *= a.ln_mask[(int64_t)b * a.ln_mask_bs + min(nw + sel * 32 + l32, a.ncols - 1)];
+    }
     if constexpr (TN == 1) {
       mean[0] = mu;
       rstd[0] = rs;
@@ -455,13 +478,15 @@ __global__ __launch_bounds__(512, 1) void bgemm_kernel(const hsp_conv1d_args a, 
 #undef BG_STAMP
 }
 
-template <int TM, int TN, bool LN, bool EXT>
+template <int TM, int TN, bool LN, bool EXT, bool MOD = false>
 int bg_launch(const hsp_conv1d_args& a, hipStream_t s, int n_mt, int n_nt, int total) {
   using C = BgCfg<TM, TN>;
   static hsp_lds_flags flags;
-  if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(bgemm_kernel<TM, TN, LN, EXT>), C::LDS_BYTES, flags)) return e;
+  // MOD: + the utterance's (1 + scale) vector behind the stages (Cin <= 1024 rounded up to whole stages: <= 4.2 KB)
+  const int lds_bytes = C::LDS_BYTES + (MOD ? ((a.Cin + BG_KS - 1) / BG_KS) * BG_KS * (int)sizeof(float) : 0);
+  if (int e = hsp_raise_lds_limit(reinterpret_cast<const void*>(bgemm_kernel<TM, TN, LN, EXT, MOD>), C::LDS_BYTES + (MOD ? 4224 : 0), flags)) return e;
   const int per_xcd = (total + 7) / 8;
-  hipLaunchKernelGGL((bgemm_kernel<TM, TN, LN, EXT>), dim3((unsigned)(8 * per_xcd)), dim3(512), C::LDS_BYTES, s, a, n_mt, n_nt,
+  hipLaunchKernelGGL((bgemm_kernel<TM, TN, LN, EXT, MOD>), dim3((unsigned)(8 * per_xcd)), dim3(512), lds_bytes, s, a, n_mt, n_nt,
                      per_xcd, total);
   return (int)hipGetLastError();
 }
@@ -482,6 +507,9 @@ int bg_go(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     return 0;
   }
   if (bg_extended(a)) return bg_launch<TM, TN, false, true>(a, s, n_mt, n_nt, (int)total);   // never with ln_c1 (hsp_bgemm_try)
+  if constexpr (TM == 1 && TN == 1) {
+    if (a.ln_scale) return bg_launch<1, 1, true, false, true>(a, s, n_mt, n_nt, (int)total);   // modulated LayerNorm: 64 x 64 only
+  }
   return a.ln_c1 ? bg_launch<TM, TN, true, false>(a, s, n_mt, n_nt, (int)total)
                  : bg_launch<TM, TN, false, false>(a, s, n_mt, n_nt, (int)total);
 }
@@ -498,6 +526,8 @@ int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   if ((a.Cin & 3) || (a.ncols & 3) || (a.x_bs & 3) || (a.x_cs & 3) || !al16(a.x) || !al16(a.w) || (a.w_ld & 3)) return -1;
   if (a.Cin < 96 || a.Cin > 8192) return -1;
   if (a.ln_c1 && !(a.ln_eps > 0.0f)) return -1;
+  if (a.ln_scale && (!a.ln_c1 || a.bias || !a.cbias || a.Cin > 1024 || a.act != HSP_ACT_NONE || a.res)) return -1;   // hsp.h ln_scale
+  if (!a.ln_scale && (a.ln_mask || a.ln_c1_bs)) return -1;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return -1;
   if (a.act != HSP_ACT_NONE && a.act != HSP_ACT_RELU && a.act != HSP_ACT_GELU_TANH) return -1;
   // the epilogues address a row as uniform base + 32-bit lane offset and test bounds per group of four rows
@@ -524,6 +554,7 @@ int hsp_bgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   auto tiles = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.ncols + bn - 1) / bn) * a.B; };
   auto waste_ok = [&](int bm) { return 4 * (int64_t)(((a.M + bm - 1) / bm) * bm - a.M) <= a.M; };
   const int64_t t64 = tiles(64, 64);
+  if (a.ln_scale) return bg_go<1, 1>(a, s, plan_out);     // the modulated LayerNorm: this kernel's 64 x 64 shape or nothing
   if (t64 < 96 && !a.split_row) return -1;   // (a second-output launch has no other kernel: better one launch here than two)
   // (round 4, tools/gemm_sweep.py over B in {1..64} x T in {50, 200, 1000}: profiles/r04_gemm_dispatch_table.txt)  The
   // 128 x 128 shape runs one workgroup per CU, so what it costs is ROUNDS of 256 tiles: it wins only for many rows

@@ -31,6 +31,8 @@ int validate(const hsp_conv1d_args& a) {
   if (!a.zeros || (reinterpret_cast<uintptr_t>(a.zeros) & 15) != 0) return HSP_EINVAL;
   if (a.prologue != HSP_PRO_NONE && a.prologue != HSP_PRO_LRELU && a.prologue != HSP_PRO_ACT1D) return HSP_EINVAL;
   if (a.mask_mode != HSP_MASK_NONE && !a.mask) return HSP_EINVAL;
+  // modulated input LayerNorm (hsp.h ln_scale): with ln_c1 only; its per-utterance bias arrives as cbias
+  if ((a.ln_scale || a.ln_mask || a.ln_c1_bs) && (!a.ln_c1 || !a.ln_scale || a.bias || !a.cbias || a.Cin > 1024 || a.ln_c1_bs < 0)) return HSP_EINVAL;
   if (a.rows == HSP_ROWS_GATE_WN || a.rows == HSP_ROWS_GATE_GLU) {
     if (a.gate_half <= 0 || (a.gate_half & 31) || a.M != 2 * a.gate_half || a.Cout != a.gate_half) return HSP_EINVAL;
     if (a.prologue == HSP_PRO_ACT1D) return HSP_EINVAL;
@@ -61,6 +63,7 @@ int dispatch(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
     const int e = hsp_bgemm_try(a, s, plan_out);
     if (e >= 0) return e;
   }
+  if (a.ln_scale) return HSP_EINVAL;              // the modulated LayerNorm exists on the block token GEMM only
   // (tuning bit 1 << 24: try the register-path token GEMM whatever the launch size -- tools/gemm_sweep.py)
   if ((short_seq || a.ln_c1 || a.split_row || HSP_DBG(a, 1 << 24)) && !a.w_bs && !HSP_DBG(a, 128)) {
     // 1x1 GEMMs over a few thousand token columns: the register-path kernel (hsp_rgemm.hip).  (The LDS-DMA token GEMM

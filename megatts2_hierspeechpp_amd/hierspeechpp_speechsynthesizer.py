@@ -30,7 +30,7 @@ from . import activations
 from . import modules
 from .alias_free_torch import Activation1d
 from .commons import get_padding
-from .hip_layers import Conv1d, ConvTranspose1d, Linear, StackedLinearCT, entry as _entry, finalize as _finalize
+from .hip_layers import Conv1d, ConvTranspose1d, Linear, ModulatedNormRows, StackedLinearCT, entry as _entry, finalize as _finalize
 from .styleencoder import StyleEncoder
 
 UNUSED_PREFIXES = ("enc_p.", "enc_q.", "mel_decoder.", "emb.")  # training / analysis only
@@ -68,8 +68,15 @@ class ResidualCouplingBlock_Transformer(nn.Module):
         lins = [blk.adaLN_modulation[1] for i in range(n_flows) for blk in self.flows[2 * i].enc_block]
         for lin in lins:
             lin.__dict__["_stacked_elsewhere"] = True
-        self.adaln_all = StackedLinearCT(lins)
         self._mod_rows = lins[0].cout * n_layers   # rows per coupling layer
+        # (round 6) ... and, behind them, per block the (c1_b | bias_b) rows its qkv layer needs to run norm1 + modulate
+        # inside its own GEMM (hip_layers.ModulatedNormRows: 6 * hidden rows per block as well)
+        self._modq_base = None
+        if modules.FOLD_LN:
+            blocks = [blk for i in range(n_flows) for blk in self.flows[2 * i].enc_block]
+            self._modq_base = sum(l.cout for l in lins)
+            lins = lins + [ModulatedNormRows(blk.attn.qkv, blk.adaLN_modulation[1]) for blk in blocks]
+        self.adaln_all = StackedLinearCT(lins)
         # (round 6)  The Flips cost no launch: reverse runs `Flip, coupling` for i = n_flows - 1 ... 0, so the tensor
         # reaches coupling i after n_flows - i flips; the layers that see an odd number of them work on the reversed
         # channel axis through their packed weights (set_flipped).  n_flows odd leaves one real Flip at the end.
@@ -95,7 +102,9 @@ class ResidualCouplingBlock_Transformer(nn.Module):
                 owned = True
             else:
                 flipped = not flipped                                                           # Flip, not launched
-            x = layer(x, x_mask, g=None, mods=mods[:, i * R:(i + 1) * R], reverse=True, inplace=owned)   # coupling
+            q0 = self._modq_base
+            x = layer(x, x_mask, g=None, mods=mods[:, i * R:(i + 1) * R], reverse=True, inplace=owned,
+                      modq=None if q0 is None else mods[:, q0 + i * R:q0 + (i + 1) * R])                 # coupling
             owned = True
         return Fh.flip_channels(x) if flipped else x
 

@@ -691,13 +691,17 @@ class Conv1d(_ConvBase):
     # ----------------------------------------------------------------------------
     def forward(self, x, *, act1d=None, lrelu: Optional[float] = None, silu_in=False, act=L.ACT_NONE, cbias=None,
                 mask=None, mask_mode=L.MASK_NONE, cscale=None, scale=1.0, res=None, out=None, accumulate=False,
-                post_scale=1.0, force_direct=False, row_range=None, split_out=None, mask_mode2=L.MASK_NONE):
+                post_scale=1.0, force_direct=False, row_range=None, split_out=None, mask_mode2=L.MASK_NONE, ln_mod=None):
         """``row_range=(r0, r1)`` computes only output channels [r0, r1) (PLAIN rows, r0 % 4 == 0):
         the WN res/skip layer is one parameter set feeding two differently-fused launches.
         ``split_out=(split_row, out2, accumulate2)``: ONE launch for both halves of such a layer
         (hsp_conv1d_args.split_row): rows [0, split_row) -> the usual output with this call's epilogue, rows
         [split_row, cout) -> ``out2`` (+= if accumulate2; allocated when None).  Returns (out, out2), or None when
-        the library has no fused kernel for the shape (the caller then launches the halves separately)."""
+        the library has no fused kernel for the shape (the caller then launches the halves separately).
+        ``ln_mod=(scale, c1, bias_b, mask, eps)``: the modulated input LayerNorm of a DiT block inside this 1x1 layer's
+        GEMM (hsp_conv1d_args.ln_scale): x is the UN-normalised input, ``scale`` [B, Cin], ``c1`` / ``bias_b`` [B, cout]
+        (unit inner stride) the per-utterance vectors of include/hsp.h, ``mask`` [B, 1, T] or None.  Returns None when the
+        library has no kernel for the shape (the caller then runs LayerNorm + modulate as its own launch)."""
         self._require_ready()
         B, Cin, Lin = x.shape
         assert Cin == self.cin, (Cin, self.cin)
@@ -741,6 +745,21 @@ class Conv1d(_ConvBase):
         if self.__dict__.get("_pre_norm") is not None:
             a.ln_c1, a.ln_eps = L.fptr(self._c1), float(self._pre_norm.eps)
             assert not force_direct and row_range is None
+        if ln_mod is not None:
+            sc, c1, bb, lmask, eps = ln_mod
+            assert self.k == 1 and not gated and row_range is None and split_out is None and cbias is None and \
+                self.__dict__.get("_pre_norm") is None and act1d is None
+            assert sc.shape == (B, Cin) and c1.shape == (B, cout) and bb.shape == (B, cout)
+            assert sc.stride(1) == 1 and c1.stride(1) == 1 and bb.stride(1) == 1
+            a.ln_c1, a.ln_c1_bs, a.ln_eps = L.fptr(c1), c1.stride(0), float(eps)
+            a.ln_scale, a.ln_scale_bs = L.fptr(sc), sc.stride(0)
+            a.bias, a.cbias, a.cbias_bs = None, L.fptr(bb), bb.stride(0)
+            if lmask is not None:
+                assert lmask.stride(-1) == 1 and lmask.shape[0] == B
+                a.ln_mask, a.ln_mask_bs = L.fptr(lmask), lmask.stride(0)
+            rc = _launch("hsp_conv1d_mfma_f32", L.lib().hsp_conv1d_mfma_f32, a, 2 * B * cout * Cin * Lout,
+                         4 * (B * Cin * Lin + B * cout * Lout + cout * Cin), soft=True)
+            return None if rc else out
         direct = (force_direct or self.stride != 1 or self.cin < 8 or cout < 8 or Lout < 8 or silu_in) \
             and not gated and act1d is None and self.__dict__.get("_pre_norm") is None
         if direct and a.res_ts > 1:
@@ -980,10 +999,40 @@ class StackedLinearCT(Conv1d):
         self.__dict__["_parts"] = tuple(parts)  # not registered as sub-modules (no duplicate state_dict keys)
 
     def _folded(self):
-        return torch.cat([p.weight.data for p in self._parts], 0).contiguous()
+        return torch.cat([p.stack_weight() if hasattr(p, "stack_weight") else p.weight.data for p in self._parts], 0).contiguous()
 
     def _bias_src(self):
-        return torch.cat([p.bias.data for p in self._parts], 0)
+        return torch.cat([p.stack_bias() if hasattr(p, "stack_bias") else p.bias.data for p in self._parts], 0)
+
+
+class ModulatedNormRows:
+    """Rows of a stacked conditioning GEMM that deliver, per utterance, the two vectors a modulated input LayerNorm needs
+    inside a following 1x1 layer `lin` (include/hsp.h ln_scale; modules.DiTConVBlock, modules.py:346-347,406-409):
+        c1_b   = lin.W (1 + scale_b)        bias_b = lin.W shift_b + lin.b
+    where (shift_b, scale_b) = rows [0, C) and [C, 2C) of an `ada` Linear applied to the SAME conditioning input s_b.
+    Both are linear in s_b:   c1_b = (W A_scale) s_b + (W a_scale + W 1),   bias_b = (W A_shift) s_b + (W a_shift + b)
+    -- so they are 2 cout extra rows of the GEMM that evaluates `ada` anyway (products formed in float64 when the
+    weights are packed, rounded once).  Not a module: owns no parameters, a part of a StackedLinearCT."""
+
+    def __init__(self, lin: "Conv1d", ada: "Conv1d"):
+        assert lin.k == 1 and ada.k == 1 and ada.cout >= 2 * lin.cin
+        self.lin, self.ada, self.cin, self.cout = lin, ada, ada.cin, 2 * lin.cout
+
+    def _mats(self):
+        Cc = self.lin.cin
+        W = self.lin._folded().reshape(self.lin.cout, Cc).double()
+        A = self.ada.weight.data.reshape(self.ada.cout, self.ada.cin).double()
+        ab = self.ada.bias.data.double()
+        return W, A[:Cc], A[Cc:2 * Cc], ab[:Cc], ab[Cc:2 * Cc]          # W, A_shift, A_scale, a_shift, a_scale
+
+    def stack_weight(self):
+        W, A_sh, A_sc, _, _ = self._mats()
+        return torch.cat([W @ A_sc, W @ A_sh], 0).float()
+
+    def stack_bias(self):
+        W, _, _, a_sh, a_sc = self._mats()
+        b = self.lin.bias.data.double() if self.lin.bias is not None else 0.0
+        return torch.cat([W @ a_sc + W.sum(1), W @ a_sh + b], 0).float()
 
 
 def _set_out(a, out, B, cout, Lout):

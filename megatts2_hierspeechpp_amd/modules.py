@@ -20,6 +20,14 @@ LRELU_SLOPE = 0.1  # modules.py:17
 # (round 6, VERDICT r05 item 1b: shorter dependent launch chains in the 50 Hz part)
 FOLD_MASK = os.environ.get("HSP_FOLD_MASK", "1") == "1"   # WN: the final mask multiply inside the skip launches
 FOLD_FLIP = os.environ.get("HSP_FOLD_FLIP", "1") == "1"   # coupling blocks: Flip inside the next layer's packed pre / post
+# DiT blocks: norm1 + modulate inside the qkv GEMM (hsp_conv1d_args.ln_scale) where the caller supplies the per-utterance
+# c1 / bias vectors (`modq`: extra rows of the stacked adaLN GEMM, hip_layers.ModulatedNormRows) -- 96 LayerNorm launches
+# per 32-utterance step fewer.  MEASURED AND NOT KEPT AS THE DEFAULT (round 6): same-box 59.07 ms per step
+# with the LayerNorm launched on its own against 59.17 with the fold (profiles/r06_ab_fold_ln.json) -- the launches it
+# removes were worth at most 0.38 ms (tools/front_probe.py), and the GEMM pays for the factor it multiplies into every
+# staged fragment and the adaLN GEMM for twice the rows.  Read when a model is BUILT (the extra rows are stacked then) and
+# at every call; HSP_FOLD_LN=1 switches it on, tests/test_gpu_parity.py::test_modulated_layernorm_inside_the_qkv_gemm runs it.
+FOLD_LN = os.environ.get("HSP_FOLD_LN", "0") == "1"
 
 def _fuse(x) -> bool:
     """Route a WN layer / DiT FFN through the entry points SURVEY.md 8(b) names for them (hsp_wn_layer_f32,
@@ -173,7 +181,7 @@ class DiTConVBlock(nn.Module):
         # nn.Sequential(SiLU, Linear) in the reference: index 1 carries the parameters
         self.adaLN_modulation = nn.ModuleList([nn.Identity(), Linear(hidden_size, 6 * hidden_size)])
 
-    def forward(self, x, c, x_mask, c_silu=None, mod=None, premasked=False):
+    def forward(self, x, c, x_mask, c_silu=None, mod=None, premasked=False, modq=None):
         """``c_silu`` = SiLU(c) precomputed by the caller (the same for every block of a flow); ``mod`` =
         this block's adaLN_modulation output [B, 6C, 1] when the caller ran all blocks' Linears as one GEMM;
         ``premasked``: x is already zero outside the mask (the output of a masked launch), so the leading
@@ -188,8 +196,14 @@ class DiTConVBlock(nn.Module):
         else:
             mod = self.adaLN_modulation[1](c, silu_in=True)  # [B, 6C, 1]
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = (mod[:, i * C:(i + 1) * C, 0] for i in range(6))
-        h = Fh.layernorm_mod(x, 1e-6, mask=x_mask, shift=sh_a, scale=sc_a)
-        qkv = self.attn.qkv(h)
+        qkv = None
+        if modq is not None and FOLD_LN:
+            # ``modq`` [B, 6C, 1]: (c1_b | bias_b) of the qkv layer for this block (ModulatedNormRows): LayerNorm, mask and
+            # modulate run inside the qkv GEMM on the un-normalised x; None = no kernel for this shape
+            qkv = self.attn.qkv(x, ln_mod=(sc_a, modq[:, :3 * C, 0], modq[:, 3 * C:6 * C, 0], x_mask, 1e-6))
+        if qkv is None:
+            h = Fh.layernorm_mod(x, 1e-6, mask=x_mask, shift=sh_a, scale=sc_a)
+            qkv = self.attn.qkv(h)
         if Fh.mha_proj_supported(self.attn.num_heads, C // self.attn.num_heads, C, x.shape[2]):
             # attention + proj + `x + gate_msa * (.) * mask` in ONE launch (round 4, csrc/hsp_mhaproj.hip)
             x = Fh.mha_proj(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.attn.num_heads, self.attn.scale,
@@ -236,8 +250,9 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
         self.pre.pack_flipped(inputs=self.flipped)
         self.post.pack_flipped(outputs=self.flipped)
 
-    def forward(self, x, x_mask, g=None, reverse=False, inplace=False, c_silu=None, mods=None):
-        """``mods`` [B, n_layers * 6 * hidden, 1]: the adaLN outputs of this layer's blocks, stacked."""
+    def forward(self, x, x_mask, g=None, reverse=False, inplace=False, c_silu=None, mods=None, modq=None):
+        """``mods`` [B, n_layers * 6 * hidden, 1]: the adaLN outputs of this layer's blocks, stacked; ``modq`` [B, n_layers *
+        6 * hidden, 1]: their qkv layers' (c1_b | bias_b) rows (DiTConVBlock.forward), or None."""
         if not reverse:
             raise NotImplementedError("training direction (logdet) is out of scope")
         half = self.half_channels
@@ -247,7 +262,7 @@ class ResidualCouplingLayer_Transformer_simple(nn.Module):
         for j, blk in enumerate(self.enc_block):
             # `pre` and every block's last launch multiply by the mask before the residual add: h stays masked
             h = blk(h, g, x_mask, c_silu=c_silu, mod=None if mods is None else mods[:, j * R:(j + 1) * R],
-                    premasked=True)
+                    premasked=True, modq=None if modq is None else modq[:, j * R:(j + 1) * R])
         out = x if inplace else x.clone()
         # x1 <- (x1 - post(h) * mask) * mask          (modules.py:473,486)
         self.post(h, mask=x_mask, mask_mode=L.MASK_BOTH, scale=-1.0, res=x[:, wr], out=out[:, wr])

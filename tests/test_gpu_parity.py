@@ -430,6 +430,50 @@ def test_generator_as_sequential_utterance_groups(full_model, device, monkeypatc
         monkeypatch.setattr(hss, "GEN_GROUPS", 1)
 
 
+def test_modulated_layernorm_inside_the_qkv_gemm(device, monkeypatch):
+    """hsp_conv1d_args.ln_scale (round 6): norm1 + mask + modulate of every DiT block (modules.py:346-347,406-409) inside the
+    qkv GEMM -- per-utterance (1 + scale) on the staged fragments, c1_b / bias_b from the stacked adaLN GEMM's extra rows --
+    against the same flows with the LayerNorm launched on its own (HSP_FOLD_LN off), on a ragged batch of 8 x 200 frames
+    (the bench's front-group shape: the block GEMM takes the form) and on 3 x 50 frames (T % 4 != 0: the form is refused
+    and the fallback must give the same values as before); 96 -> 0 first-LayerNorm launches counted."""
+    from megatts2_hierspeechpp_amd import hip_layers, modules, synth
+    from megatts2_hierspeechpp_amd import hierspeechpp_speechsynthesizer as hss
+    from oracle.hsp_oracle import default_config
+    monkeypatch.setattr(modules, "FOLD_LN", True)          # (off by default: the extra adaLN rows are stacked when a model is built)
+    full_model = hss.SynthesizerTrn(641, 192, **default_config())
+    full_model.load_state_dict({k: torch.from_numpy(synth.synth_tensor(k, tuple(v.shape), 0)) for k, v in full_model.state_dict().items()})
+    full_model.finalize(device)
+    for B, T, lens in ((8, 200, [200, 173, 200, 64, 200, 199, 120, 200]), (3, 50, [50, 37, 50])):
+        inp = synth.synth_inputs(B, T, seed=909 + T)
+        d = {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
+        d["length"] = torch.tensor(lens, dtype=torch.int64, device=device)
+        kinds = []
+        monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", lambda kind, fl, nb, e0, e1, la: kinds.append((kind, la)))
+        monkeypatch.setattr(hss, "FRONT_SPLITS", 1)
+        with torch.no_grad():
+            monkeypatch.setattr(modules, "FOLD_LN", True)
+            o1, e1 = full_model.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+            n_mod = sum(1 for k, la in kinds if k == "hsp_conv1d_mfma_f32" and la is not None and la.ln_scale)
+            kinds.clear()
+            monkeypatch.setattr(modules, "FOLD_LN", False)
+            o0, e0 = full_model.infer(d["mel"], d["w2v"], d["length"], d["f0"], noise=d["noise"])
+        monkeypatch.setattr(hip_layers, "LAUNCH_HOOK", None)
+        assert n_mod == (24 if T % 4 == 0 else 0), n_mod            # 2 flow stacks x 4 layers x 3 blocks
+        err = max(float((o1 - o0).abs().max()), float((e1 - e0).abs().max()) / max(1.0, float(e0.abs().max())))
+        # (24 blocks' worth of differently-rounded LayerNorms through two flows and the Generator: a third of the 1e-4 bar)
+        assert err <= (3e-5 if T % 4 == 0 else 0.0), f"{B} x {T}: folded vs launched LayerNorm differ by {err:.2e}"
+    # ... and against the oracle: one 1-s utterance with the fold on
+    from oracle import hsp_oracle as O
+    inp = synth.synth_inputs(1, 52, seed=4242)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    sd = {k: v.detach().cpu() for k, v in full_model.state_dict().items()}
+    monkeypatch.setattr(modules, "FOLD_LN", True)
+    with torch.no_grad():
+        ro, _ = O.synth_infer(sd, default_config(), t["mel"], t["w2v"], t["length"], t["f0"], t["noise"])
+        go, _ = full_model.infer(*(t[k].to(device) for k in ("mel", "w2v", "length", "f0")), noise=t["noise"].to(device))
+    _close(go.cpu().numpy(), ro.numpy(), "infer 1 x 1.04 s with the modulated LayerNorm inside the qkv GEMM")
+
+
 def test_full_size_one_utterance_vs_oracle(full_model, device):
     """One 4-s utterance of the full-size batch against the oracle (about 10 s of CPU)."""
     from megatts2_hierspeechpp_amd import synth
