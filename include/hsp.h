@@ -387,7 +387,10 @@ int hsp_plm_embed_f32(const float* tc, int64_t tc_bs, int64_t tc_cs, int32_t Dtc
 /* The same for step n >= 2 of the greedy loop with the choice of the PREVIOUS step folded in (one launch per step less):
  * first codes[b, n - 1] = argmax_c logits[b * l_bs + c * l_cs] (first maximal index on ties, as hsp_argmax_f32; the
  * value is also stored to `codes`), then x as above.  `logits` = the n_logits scores of step n - 1
- * (ttv_v1/t2w2v_transformer.py:716-717 followed by :710-713 of the next iteration). */
+ * (ttv_v1/t2w2v_transformer.py:716-717 followed by :710-713 of the next iteration).
+ * n == 1 (round 6) is the ONE-POSITION form of the loop's layer-0 cache: every per-position operand (tc, codes, pe_t, x)
+ * points at position t and only that position is chosen and embedded -- a caller that passes n == 1 with un-shifted
+ * pointers overwrites its go token. */
 int hsp_plm_embed_step_f32(const float* tc, int64_t tc_bs, int64_t tc_cs, int32_t Dtc, int64_t* codes,
                            int64_t codes_bs, const float* emb, int32_t Demb, int32_t n_emb, const float* pe_t,
                            int32_t P, const float* alpha, float* x, int64_t x_bs, int64_t x_cs, int32_t B, int32_t n,

@@ -168,7 +168,7 @@ extern "C" int hsp_plm_embed_step_f32(const float* tc, int64_t tc_bs, int64_t tc
                                       int32_t n, const float* logits, int64_t l_bs, int64_t l_cs, int32_t n_logits,
                                       void* stream) {
   if (!tc || !codes || !emb || !pe_t || !alpha || !x || !logits) return HSP_EINVAL;
-  if (B <= 0 || n < 2 || n > P || Dtc <= 0 || Demb <= 0 || n_emb <= 0 || x_bs < 0 || x_cs < n) return HSP_EINVAL;
+  if (B <= 0 || n < 1 || n > P || Dtc <= 0 || Demb <= 0 || n_emb <= 0 || x_bs < 0 || x_cs < n) return HSP_EINVAL;   // n == 1: hsp.h
   if (n_logits <= 0 || l_cs <= 0 || l_bs < 0) return HSP_EINVAL;
   const int parts = 1 + (int)(((int64_t)Dtc * n + 1023) / 1024);
   if (B > 65535 || parts > 65535) return HSP_EINVAL;

@@ -206,7 +206,9 @@ int hsp_rgemm_try(const hsp_conv1d_args& a, hipStream_t s, int32_t* plan_out) {
   if (!forced && a.x_ts == 1 && (outs > 1400000 || outs * a.Cin > 500000000)) return -1;
   // many short utterances ([B, C, T <= 64]: every utterance is two ragged 32-column tiles): beyond ~400 such tiles the
   // conv kernel's tiles win by 1.4-1.6 x, below the register path does by up to 1.8 x (profiles/r04_gemm_dispatch_table.txt)
-  if (!forced && a.ncols <= 64 && tiles(32, 32) > 400) return -1;
+  // (a fused input LayerNorm that the block GEMM did not take has no other kernel: e.g. the ONE new column per utterance of
+  // the PLM loop's cached layer 0 -- B utterances x 1 column, 26 x 16 tiles -- round 6)
+  if (!forced && !a.ln_c1 && a.ncols <= 64 && tiles(32, 32) > 400) return -1;
   // tile: 64 x 32 where that still fills the chip, else 32 x 32 (a 64 x 64 / K-split-2 form was measured and lost)
   int nbm = 1, nbn = 1;
   if (tiles(64, 32) >= 200) { nbm = 2; nbn = 1; }

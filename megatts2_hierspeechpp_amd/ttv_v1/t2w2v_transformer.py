@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -72,6 +73,12 @@ class Embedding(HipLayer):
             self._w.copy_(self.weight.data.reshape(-1))
 
 
+# (round 6)  Layer 0 of the greedy loop keeps its q / k / v of old positions: its input is the embedding
+# matrix, whose columns are final once their code is chosen, so every step embeds and projects ONE new column per utterance
+# instead of the whole prefix (transformer_mega.MultiHeadAttention.forward_cached).  HSP_PLM_CACHE_L0=0: the full re-projection.
+PLM_CACHE_L0 = os.environ.get("HSP_PLM_CACHE_L0", "1") == "1"
+
+
 class Megatts2PLM1(nn.Module):
     """t2w2v_transformer.Megatts2PLM1 (:627-718): greedy prosody-code generation.
 
@@ -119,8 +126,28 @@ class Megatts2PLM1(nn.Module):
                     "hsp_plm_embed_step_f32")
         return x
 
+    def _embed_one(self, tc, codes, t, cache, prev_logits):
+        """Position t of every utterance into ``cache.emb[:, :, t]`` ([D, B, Tp]: fixed pitch) -- the same launch as _embed
+        with every per-position operand shifted to column t and n = 1 (the kernel then takes codes[:, t] = argmax of
+        ``prev_logits`` first, as in the full form)."""
+        B = tc.shape[0]
+        emb = cache.emb
+        x_t = emb[:, :, t]                                           # [D, B] view: element (c, b) at c * B Tp + b Tp
+        tc_t, codes_t = tc[:, :, t], codes[:, t]
+        pe_t = self.pos_emb._pe_t[t:]                                # flat [D][N_POS] table: row c, position t at c * N_POS + t
+        head = (L.fptr(tc_t), tc.stride(0), tc.stride(1), self.tc_latent_dim, L.ptr(codes_t), codes.stride(0),
+                L.fptr(self.pc_embedding._w), self.vq_dim, self.pc_embedding.num_embeddings, L.fptr(pe_t),
+                self.pos_emb.N_POS, L.fptr(self.pos_emb._alpha), L.fptr(x_t), emb.stride(1), emb.stride(0), B, 1)
+        if prev_logits is None:
+            L.check(L.lib().hsp_plm_embed_f32(*head, L.stream_ptr()), "hsp_plm_embed_f32")
+        else:
+            lg = prev_logits
+            assert lg.shape == (1, self.vq_bins, B) and lg.stride(2) == 1
+            L.check(L.lib().hsp_plm_embed_step_f32(*head, L.fptr(lg), 1, lg.stride(1), self.vq_bins, L.stream_ptr()),
+                    "hsp_plm_embed_step_f32")
+
     @_entry
-    def step_logits(self, tc_latent, codes, n, out=None, prev_logits=None):
+    def step_logits(self, tc_latent, codes, n, out=None, prev_logits=None, cache=None):
         """Logits of position n-1 given the first n columns of ``tc_latent`` [B, 256, T] and of
         ``codes`` [B, >= n] (go token first): one pass of the loop body (:710-716) -> [1, vq_bins, B].
         With ``prev_logits`` (the result of the call for n-1) ``codes[:, n-1]`` is not read but first set to their
@@ -129,7 +156,19 @@ class Megatts2PLM1(nn.Module):
         # the last layer only produces the last position of every utterance when those B columns form a
         # 16-B addressable matrix for the fused-LayerNorm GEMM; otherwise it runs in full
         last_only = B % 4 == 0
-        x = self.plm(self._embed(tc_latent, codes, n, prev_logits), batch=(B, n), last_only=last_only)
+        att = self.plm.layers[0].attn
+        if cache is not None:
+            # layer 0 incrementally (PLM_CACHE_L0): only position n - 1 is embedded and projected, the older columns are kept
+            self._embed_one(tc_latent, codes, n - 1, cache, prev_logits)
+        if cache is not None and Fh.mha_proj_supported(att.n_heads, att.head_dim, self.d_model, n):
+            x = self.plm(None, batch=(B, n), last_only=last_only, cache=cache)
+        elif cache is not None:
+            # the first three steps (fewer than four keys: no fused attention kernel): the new column still enters the cache,
+            # the step itself runs in the full form (its embedding launch takes the same argmax again: idempotent)
+            att.qkv(cache.emb[:, :, n - 1:n].permute(1, 0, 2), out=cache.qkv[:, :, n - 1:n].permute(1, 0, 2))
+            x = self.plm(self._embed(tc_latent, codes, n, prev_logits), batch=(B, n), last_only=last_only)
+        else:
+            x = self.plm(self._embed(tc_latent, codes, n, prev_logits), batch=(B, n), last_only=last_only)
         if not last_only:
             x = Fh.copy_strided(x[0][:, :B * n].reshape(self.d_model, B, n)[:, :, n - 1].unsqueeze(0))
         return self.predict_layer(x, out=out)
@@ -147,10 +186,18 @@ class Megatts2PLM1(nn.Module):
         all_logits = torch.empty(T, self.vq_bins, B, dtype=torch.float32, device=tc_latent.device) if return_logits \
             else None
         lg = None
+        cache = None
+        if PLM_CACHE_L0 and self.plm.num_layers > 1 and \
+                Fh.mha_proj_supported(self.plm.layers[0].attn.n_heads, self.plm.layers[0].attn.head_dim, self.d_model, T):
+            import types
+            Tp = (T + 3) & ~3
+            cache = types.SimpleNamespace(
+                emb=torch.empty(self.d_model, B, Tp, dtype=torch.float32, device=tc_latent.device),
+                qkv=torch.empty(3 * self.d_model, B, Tp, dtype=torch.float32, device=tc_latent.device))
         for t in range(T):
             # the greedy choice of step t-1 is taken inside step t's embedding launch; only the last step's needs its own
             lg = self.step_logits(tc_latent, codes, t + 1, out=all_logits[t:t + 1] if return_logits else None,
-                                  prev_logits=lg)
+                                  prev_logits=lg, cache=cache)
         L.check(L.lib().hsp_argmax_f32(L.fptr(lg), 1, B, B, self.vq_bins, L.ptr(codes[:, T:]), codes.stride(0),
                                        L.stream_ptr()), "hsp_argmax_f32")
         return (codes[:, 1:], all_logits.permute(2, 0, 1)) if return_logits else codes[:, 1:]

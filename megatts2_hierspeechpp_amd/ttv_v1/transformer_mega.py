@@ -62,6 +62,28 @@ class MultiHeadAttention(nn.Module):
         self.out_proj = nn.ModuleList([LinearCT(qkv_dim, qkv_dim)])  # nn.Sequential(Linear, Dropout): key "out_proj.0"
         self.out_proj[0].keep_rowmajor_weight()   # A operand of the projection inside hsp_mha_proj_f32
 
+    def forward_cached(self, cache, n, out_cols):
+        """Layer 0 of the greedy loop with its q / k / v of OLD positions kept (round 6, VERDICT r05 item 3's small win): the
+        layer's input is the embedding matrix, whose columns do not change once their code is chosen
+        (t2w2v_transformer.py:708-716: position j of step t is position j of every later step), and q / k / v are
+        per-column functions of it, so step t computes the ONE new column per utterance -- a [3D x B] LayerNorm-GEMM
+        instead of [3D x B n] -- into ``cache.qkv`` [3D, B, Tp] beside the ``cache.emb`` [D, B, Tp] it was computed from.
+        Attention reads the first n columns of every utterance through strided views; the output (+ residual = the
+        embeddings) goes to the side-by-side layout [1, D, Np] the rest of the step works in."""
+        D, B, Tp = self.qkv_dim, cache.emb.shape[1], cache.emb.shape[2]
+        t = n - 1
+        xin = cache.emb[:, :, t:t + 1].permute(1, 0, 2)            # [B, D, 1]: utterances as the batch, ONE column each
+        self.qkv(xin, out=cache.qkv[:, :, t:t + 1].permute(1, 0, 2))
+        per = lambda m: m[:, :, :n].permute(1, 0, 2)               # [B, C, n] view of a [C, B, Tp] matrix
+        q, k, v = (per(cache.qkv[i * D:(i + 1) * D]) for i in range(3))
+        Np = (B * n + 3) & ~3
+        y = torch.empty(1, D, Np, dtype=torch.float32, device=cache.emb.device) if Np == B * n else \
+            torch.zeros(1, D, Np, dtype=torch.float32, device=cache.emb.device)
+        lin = self.out_proj[0]
+        Fh.mha_proj(q, k, v, self.n_heads, 1.0 / math.sqrt(self.head_dim), lin._wt, bias=lin._b, res=per(cache.emb),
+                    out=out_cols(y))
+        return y
+
     def forward(self, x, kv=None, mask=None, res=None, batch=None, last_only=False):
         """x [1, D, B*T] -> out_proj(attention) [+ res]; ``last_only`` -> [1, D, B]: only the last
         position of every utterance (columns T-1, 2T-1, ...), ``res`` then being [1, D, B] already."""
@@ -114,9 +136,15 @@ class TransformerEncoderLayer(nn.Module):
         self.ff = nn.ModuleDict({"0": LinearCT(dim, ff_dim), "3": LinearCT(ff_dim, dim)})
         self.ff["0"].fuse_input_layernorm(self.norm2)
 
-    def forward(self, x, mask=None, batch=None, last_only=False):
+    def forward(self, x, mask=None, batch=None, last_only=False, cache=None):
         """``last_only`` returns just the last position of every utterance ``[1, D, B]`` (all the
-        greedy loop reads from the final layer); attention still sees the whole prefix."""
+        greedy loop reads from the final layer); attention still sees the whole prefix.  ``cache`` (layer 0 of the greedy
+        loop): x is None, the layer input lives in ``cache.emb`` (MultiHeadAttention.forward_cached)."""
+        if cache is not None:
+            B, T = batch
+            x = self.attn.forward_cached(cache, T, lambda y: y[0][:, :B * T].reshape(-1, B, T).permute(1, 0, 2))
+            h = self.ff["0"](x, act=L.ACT_RELU)
+            return self.ff["3"](h, res=x)
         res = x
         if last_only:
             B, T = batch
@@ -137,11 +165,12 @@ class TransformerEncoder(nn.Module):
                                            for _ in range(num_layers - 1)])
         self.num_layers, self.norm = num_layers, norm
 
-    def forward(self, x, x_lens=None, causal=False, batch=None, last_only=False):
+    def forward(self, x, x_lens=None, causal=False, batch=None, last_only=False, cache=None):
         if x_lens is not None or causal:
             raise NotImplementedError("length / causal masks belong to the training forward, not to infer()")
         for i, layer in enumerate(self.layers):
-            x = layer(x, batch=batch, last_only=last_only and i == self.num_layers - 1)
+            x = layer(x, batch=batch, last_only=last_only and i == self.num_layers - 1,
+                      cache=cache if i == 0 and self.num_layers > 1 else None)
         if self.norm is not None:
             x = self.norm(x)
         return x
