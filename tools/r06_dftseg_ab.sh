@@ -2,6 +2,9 @@
 #   gpurun -- 'bash tools/r06_dftseg_ab.sh'
 # kernel stats of tools/dftseg_eager.py under the baseline library (megatts2_hierspeechpp_amd/libhsp_base.so, a build of the
 # round-5 kernel sources) and under the current one, then the step A/B (tools/lib_ab.py).
+# The baseline library is not kept in the tree: build it from the commit to compare against, e.g.
+#   git stash; git checkout 81413a4 -- megatts2_hierspeechpp_amd/csrc include; make -C megatts2_hierspeechpp_amd/csrc lib
+#   cp megatts2_hierspeechpp_amd/libhsp.so megatts2_hierspeechpp_amd/libhsp_base.so; git checkout HEAD -- megatts2_hierspeechpp_amd/csrc include; git stash pop; make ... lib
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for tag in base new; do
