@@ -595,8 +595,10 @@ __device__ __forceinline__ void ds_inv_scatter_d(float* rp, int d, int i0, int h
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int cr = (r & 3) + 8 * (r >> 2);
-    // 2 (32 wh + cr + 4 half) + eo <= 63 < hop for every wh = 0 wave (hop >= 65: k <= 64); wh = 1 and r < 12: <= 95
-    if (wh == 0 || (r < 12 && hop >= 96) || i0 + 2 * cr < hop) rp[2 * (D ? D : d) * cr] = acc[r] + acc2[r];
+    // sample 2 (32 wh + cr + 4 half) + eo of the segment: <= 63 < hop for every wh = 0 wave (hop >= 65: k <= 64); wh = 1:
+    // <= 95 for r < 8 (cr <= 11), <= 111 for r < 12 (cr <= 19), <= 127 beyond -- the uniform tests settle the registers a
+    // hop leaves whole, the per-lane compare the rest (k = 7 / 11: hop 122 / 118, the last four registers)
+    if (wh == 0 || (r < 8 && hop >= 96) || (r < 12 && hop >= 112) || i0 + 2 * cr < hop) rp[2 * (D ? D : d) * cr] = acc[r] + acc2[r];
   }
 }
 // (the dilations of the AMP blocks -- 1, 3, 5 -- with the sample stride as an immediate offset of the LDS store)

@@ -859,7 +859,14 @@ def test_fused_attention_projection_vs_torch(H, D, B, Tq, Tk, form, device):
 
 
 @pytest.mark.parametrize("C_,k,d,L,B", [(32, 11, 1, 500, 2), (32, 7, 3, 333, 2), (128, 11, 5, 1000, 1), (48, 11, 3, 118, 3),
-                                        (64, 7, 1, 122, 1), (32, 3, 5, 37, 2), (128, 7, 5, 4000, 2)])
+                                        (64, 7, 1, 122, 1), (32, 3, 5, 37, 2), (128, 7, 5, 4000, 2),
+                                        # (round 6) the corners of the rewritten index arithmetic: hop = 96 / 94 / 66 (the
+                                        # scatter's compile-time `sample < hop` cases), dilations without an immediate-offset
+                                        # instantiation (2, 4, 8), rows cut into chunks (one LDS stretch does not hold them)
+                                        # with a length off the 16-B grid (scalar epilogue)
+                                        (32, 33, 2, 700, 2), (32, 35, 1, 300, 2), (32, 63, 1, 500, 1), (64, 11, 8, 900, 2),
+                                        (32, 11, 4, 40000, 1), (32, 21, 2, 17001, 1), (32, 29, 1, 700, 1), (32, 19, 3, 1000, 2),
+                                        (32, 17, 1, 452, 2), (32, 31, 2, 96, 1)])
 def test_frequency_domain_conv_vs_torch(C_, k, d, L, B, device):
     """Conv1d.forward_fft -- overlap-save with a 128-point DFT (hsp_dftseg_fwd_f32, one batched 1x1 product over the 64
     bins, hsp_dftseg_inv_f32) -- against torch's direct conv in float64, with the epilogue forms the AMP blocks use
@@ -1760,7 +1767,11 @@ def test_frequency_domain_conv_with_its_activation_fused(C_, k, d, L, B, device)
 @pytest.mark.parametrize("C_,k,d,L,B,k2", [(128, 11, 1, 1600, 2, 11), (128, 11, 3, 800, 2, 11), (128, 7, 5, 1000, 3, 7),
                                            (128, 11, 1, 100, 2, 11), (128, 7, 1, 236, 2, 7), (128, 11, 1, 16000, 1, 11),
                                            (128, 7, 5, 16000, 1, 7), (256, 7, 3, 4000, 2, 7), (512, 11, 5, 52, 2, 11),
-                                           (128, 11, 1, 33000, 1, 11), (136, 11, 3, 1204, 2, 7), (128, 5, 2, 600, 2, 9)])
+                                           (128, 11, 1, 33000, 1, 11), (136, 11, 3, 1204, 2, 7), (128, 5, 2, 600, 2, 9),
+                                           # (round 6) hops of 100 / 108 / 96 / 94: the inverse phase's compile-time `sample < hop`
+                                           # cases (a first rewrite let registers 8-11 of the odd wave halves through for
+                                           # 96 <= hop < 112 -- k = 18 ... 33 -- which no conv of the reference has)
+                                           (64, 29, 1, 900, 2, 21), (64, 33, 2, 700, 2, 35), (64, 19, 1, 1000, 1, 31)])
 def test_frequency_domain_conv_pair_in_one_launch(C_, k, d, L, B, k2, device):
     """Conv1d.forward_fft_pair: c2(a2(c1(a1(x)))) + res with the inverse transform of c1, c1's bias, a2 and the forward
     transform of c2 in ONE launch (hsp_dftseg_pair_f32; the tensor between the convs only in LDS) against the same two
