@@ -1301,6 +1301,28 @@ def test_plm_small_batches_match_single_rows(device):
     assert torch.equal(m.infer(tc), single)
 
 
+@pytest.mark.parametrize("B,T", [(2, 13), (5, 9), (1, 5), (4, 18)])
+def test_plm_layer0_cache_codes_vs_oracle(B, T, device, monkeypatch):
+    """The greedy loop with layer 0's q / k / v of old positions kept (HSP_PLM_CACHE_L0, round 6) at lengths off the 4-column
+    grid of the cache's pitch and batches on / off the last layer's MFMA path: the codes equal the oracle's
+    (t2w2v_transformer.py:702-718 restated) and those of the full re-projection, the logits agree to 1e-4 of their range."""
+    from megatts2_hierspeechpp_amd import synth
+    from megatts2_hierspeechpp_amd.ttv_v1 import t2w2v_transformer as T2
+    from oracle import hsp_oracle as O
+    m = T2.Megatts2PLM1()
+    sd = {k: torch.from_numpy(synth.synth_tensor("plm." + k, tuple(v.shape), 5)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(device)
+    tc = torch.from_numpy(np.random.default_rng(100 * B + T).standard_normal((B, 256, T)).astype(np.float32))
+    want = torch.cat([O.plm_infer({"plm." + k: v for k, v in sd.items()}, "plm", tc[b:b + 1]) for b in range(B)])
+    monkeypatch.setattr(T2, "PLM_CACHE_L0", True)
+    c1, l1 = m.infer(tc.to(device), return_logits=True)
+    monkeypatch.setattr(T2, "PLM_CACHE_L0", False)
+    c0, l0 = m.infer(tc.to(device), return_logits=True)
+    assert torch.equal(c1.cpu(), want) and torch.equal(c0.cpu(), want)
+    assert float((l1 - l0).abs().max()) <= 1e-4 * float(l0.abs().max())
+
+
 def test_token_gemm_reads_a_strided_residual_in_place(device):
     """hsp_conv1d_args.res_ts: the last layer of the PLM loop adds the LAST position of every utterance (columns T-1,
     2T-1, ... of the layer input) to a [D, B] product without a gather launch; other kernels refuse such a residual."""
